@@ -1,0 +1,165 @@
+"""Known-answer tests for the CPU oracle, derived by hand from the reference lines cited in
+oracle/projector_oracle.c (K1 wall, K2 occlusion, K3 miss, K4 accumulate,
+K5 RGB).  These pin the oracle; the reference itself holds no fixture for this path."""
+import numpy as np
+import pytest
+
+
+def _wall_scene(planes, dim=(8, 17, 17)):
+    """Grid [Z,Y,X]=dim, origin (-8,-8,0), vs 1; each z in ``planes`` fully filled.
+    ID of cell (z,y,x) = 1 + (plane_rank*Y + y)*X + x."""
+    Z, Y, X = dim
+    occ = np.zeros((1, Z, Y, X), np.int64)
+    for r, z in enumerate(planes):
+        occ[0, z] = 1 + (r * Y + np.arange(Y)[:, None]) * X + np.arange(X)[None, :]
+    return occ, np.array([-8.0, -8.0, 0.0], np.float32)
+
+
+def _run(oracle, occ, origin, feats, W=8, H=8, inc=0.25, count=None, out=None):
+    C = feats.shape[-1]
+    n_rows = int(occ.max()) + 1
+    count = np.zeros(n_rows, np.int32) if count is None else count
+    out = np.zeros((n_rows, C), np.float32) if out is None else out
+    vmi = np.eye(4, dtype=np.float32).reshape(-1)
+    intr = np.array([[W / 2, H / 2, W / 2, H / 2]], np.float32)
+    opts = np.array([W, H, 0.01, 10.0, inc], np.float32)
+    r = oracle.project_features(feats, occ, vmi, intr, opts, origin, 1.0, count, out, want_f64=True)
+    assert r["rc"] == 0
+    return r["hits"][0, 0], count, out
+
+
+def test_k1_centre_pixel_by_hand(oracle_mod):
+    # pixel (4,4) = principal point: dir (0,0,1), t0 = 0.01, z_k = 0.01 + 0.25 k (fp32 repeated add);
+    # first k with roundf(z_k) == 5 is k = 18 (z = 4.51) -> cell (x=8, y=8, z=5) -> ID 1 + 8*17 + 8.
+    occ, origin = _wall_scene([5])
+    feats = np.ones((1, 1, 8, 8, 4), np.float32)
+    hits, count, out = _run(oracle_mod, occ, origin, feats)
+    assert hits[4, 4] == 1 + 8 * 17 + 8 == 145
+
+
+def test_k1_wall_closed_form(oracle_mod):
+    # Every pixel (x,y): dir = ((x-4)/4, (y-4)/4, 1)/|.|; sample k sits at depth z_k = 0.01 + 0.25 k,
+    # world = z_k * ((x-4)/4, (y-4)/4, 1); first hit at k = 18 -> cell (round(wx+8), round(wy+8), 5).
+    occ, origin = _wall_scene([5])
+    W = H = 8
+    rng = np.random.default_rng(1)
+    feats = rng.standard_normal((1, 1, H, W, 4)).astype(np.float32)
+    hits, count, out = _run(oracle_mod, occ, origin, feats)
+    z = 0.01 + 0.25 * 18
+    exp_count = np.zeros_like(count)
+    exp_sum = np.zeros(out.shape, np.float64)
+    n_checked = 0
+    for y in range(H):
+        for x in range(W):
+            wx, wy = z * (x - 4) / 4 + 8, z * (y - 4) / 4 + 8
+            if min(abs(wx % 1 - 0.5), abs(wy % 1 - 0.5)) < 1e-3:
+                continue  # knife edge: fp32 vs real arithmetic may legitimately differ
+            ix, iy = int(np.floor(wx + 0.5)), int(np.floor(wy + 0.5))
+            exp = 1 + iy * 17 + ix
+            # Q9: the (u,v) bounds test may drop pixels with x == 0 or y == 0; everything else must hit
+            if x > 0 and y > 0:
+                assert hits[y, x] == exp, (x, y)
+                n_checked += 1
+            else:
+                assert hits[y, x] in (0, exp)
+    assert n_checked >= 40
+    # count / sum consistency with the hit image (K.cu:77,85-91)
+    for y in range(H):
+        for x in range(W):
+            if hits[y, x]:
+                exp_count[hits[y, x]] += 1
+                exp_sum[hits[y, x]] += feats[0, 0, y, x]
+    assert np.array_equal(count, exp_count)
+    np.testing.assert_allclose(out, exp_sum, rtol=1e-6, atol=1e-6)
+    assert count[0] == 0 and not out[0].any()          # row 0 is a dummy (Q4)
+
+
+def test_k2_occlusion(oracle_mod):
+    occ, origin = _wall_scene([3, 6])
+    feats = np.ones((1, 1, 8, 8, 2), np.float32)
+    hits, count, out = _run(oracle_mod, occ, origin, feats)
+    ids_z3 = set(occ[0, 3].reshape(-1).tolist())
+    assert hits.any()
+    assert set(np.unique(hits[hits > 0]).tolist()) <= ids_z3
+    assert count[17 * 17 + 1:].sum() == 0               # nothing behind the first wall
+    assert hits[4, 4] == 1 + 8 * 17 + 8                 # z_k >= 2.5 first at k = 10 (2.51)
+
+
+def test_k3_miss_leaves_outputs_untouched(oracle_mod):
+    occ = np.zeros((1, 8, 17, 17), np.int64)
+    origin = np.array([-8, -8, 0], np.float32)
+    feats = np.ones((1, 1, 8, 8, 3), np.float32)
+    count = np.full(5, 7, np.int32)
+    out = np.full((5, 3), 2.5, np.float32)
+    hits, count, out = _run(oracle_mod, occ, origin, feats, count=count, out=out)
+    assert not hits.any() and (count == 7).all() and (out == 2.5).all()
+
+
+def test_k4_accumulates_in_place(oracle_mod):
+    occ, origin = _wall_scene([5])
+    rng = np.random.default_rng(2)
+    feats = rng.standard_normal((1, 1, 8, 8, 4)).astype(np.float32)
+    _, c1, o1 = _run(oracle_mod, occ, origin, feats)
+    _, c2, o2 = _run(oracle_mod, occ, origin, feats, count=c1.copy(), out=o1.copy())
+    assert np.array_equal(c2, 2 * c1)
+    np.testing.assert_allclose(o2, 2 * o1, rtol=1e-6)
+
+
+def test_step_count_and_range(oracle_mod):
+    # K.cu:31-33,47,81: t runs from dmin/camDir.z while t < dmax/camDir.z in steps of inc.
+    occ = np.zeros((1, 4, 4, 4), np.int64)
+    vmi = np.eye(4, dtype=np.float32).reshape(-1)
+    intr = np.array([[4, 4, 4, 4]], np.float32)
+    opts = np.array([8, 8, 0.01, 10.0, 0.25], np.float32)
+    _, steps = oracle_mod.first_hit(occ, vmi, intr, opts, np.zeros(3, np.float32), 1.0, 1, 1, want_steps=True)
+    # centre pixel: t = 0.01 + 0.25 k < 10  ->  k = 0..39  -> 40 trips
+    assert steps[0, 0, 4, 4] == 40
+    # corner pixel (0,0): camDir.z = 1/sqrt(3): t0 = 0.01*sqrt3, tEnd = 10*sqrt3 = 17.32 -> 70 trips
+    assert steps[0, 0, 0, 0] == 70
+
+
+def test_k5_rgb_three_voxels(oracle_mod):
+    # debug_project_colors.py:54-81.  Identity pose at the origin, fx=fy=10, cx=cy=2, 4x4 image.
+    # voxel A centre (0,0,2)    -> u=v=2            -> hit, colour img[2,2]
+    # voxel B centre (0,0,-1)   -> cam.z <= 0       -> skipped (:65)
+    # voxel C centre (0.4,0,2)  -> u = 10*0.2+2 = 4 -> u_int == W -> rejected (:69)
+    # voxel D centre (0.1,0,2)  -> u = 2.5 -> Python round -> 2 (half to even), v = 2
+    # voxel E centre (0.3,0,2)  -> u = 3.5 -> 4 -> rejected
+    vs = 0.1
+    origin = np.array([-1.0, -1.0, -1.0], np.float32)
+    cells = {"A": (10, 10, 30), "B": (10, 10, 0), "C": (14, 10, 30), "D": (11, 10, 30), "E": (13, 10, 30)}
+    occ = np.zeros((31, 21, 21), np.int32)
+    for i, (x, y, z) in enumerate(cells.values()):
+        occ[z, y, x] = i + 1
+    img = np.arange(4 * 4 * 3, dtype=np.uint8).reshape(4, 4, 3)
+    c2w = np.eye(4, dtype=np.float32)
+    colors, zyx, uv = oracle_mod.rgb_project(occ, c2w, np.array([10, 10, 2, 2], np.float32), origin, vs, img)
+    got = {tuple(k): (tuple(p), c) for k, p, c in zip(zyx.tolist(), uv.tolist(), colors)}
+    # float32 origin -1.0 + 0.1*k is not exact, so D/E sit a hair off the half-integers; accept only
+    # what the float64 formula gives, computed here the long way:
+    exp = {}
+    for name, (x, y, z) in cells.items():
+        w = origin.astype(np.float64) + vs * np.array([x, y, z])
+        if w[2] > 0:
+            u, v = 10 * (w[0] / w[2]) + 2, 10 * (w[1] / w[2]) + 2
+            ui, vi = int(round(u)), int(round(v))
+            if 0 <= ui < 4 and 0 <= vi < 4:
+                exp[(z, y, x)] = (ui, vi)
+    assert (30, 10, 10) in exp and (0, 10, 10) not in exp and (30, 10, 14) not in exp
+    assert set(got) == set(exp)
+    for k, (ui, vi) in exp.items():
+        assert got[k][0] == (ui, vi)
+        np.testing.assert_array_equal(got[k][1], (img[vi, ui] / 255.0).astype(np.float32))
+    # raster (z,y,x) visiting order of np.nonzero (:50,58)
+    assert zyx.tolist() == sorted(zyx.tolist())
+
+
+def test_bso_build_occupancy(oracle_mod):
+    # build_sparse_occupancy.py:32-46: np.round is half-to-even; later duplicates overwrite (Q12)
+    pts = np.array([[0.0, 0.0, 0.0], [0.1, 0.0, 0.0], [0.05, 0.0, 0.0], [0.15, 0.2, 0.1], [0.1, 0.0, 0.0]], np.float32)
+    occ = oracle_mod.build_occupancy(pts, [0, 0, 0], 0.1)
+    assert occ.shape == (2, 3, 3)          # dims (x,y,z) = (3,3,2) reversed
+    assert occ[0, 0, 0] == 3               # 0.05/0.1 = 0.5 -> 0 (even), overwrites ID 1
+    assert occ[0, 0, 1] == 5               # ID 2 overwritten by ID 5
+    assert occ[1, 2, 2] == 4               # 1.5 -> 2 (even)
+    assert (occ > 0).sum() == 3
