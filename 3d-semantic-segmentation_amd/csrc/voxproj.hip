@@ -1,0 +1,614 @@
+// voxproj.hip -- MI355X (gfx950) 2D -> sparse-voxel feature projector: kernels + C-ABI.
+//
+// Replaces the device path of the reference's project_features_cuda extension
+// (cuda_project_image_to_sparse_voxel/project_image_cuda_kernel.cu:24-92,140-334,374-459) with a
+// two-phase design written for CDNA4:
+//
+//   phase 1  k_first_hit   one lane per (pixel, view): the reference's ray-march replayed in the
+//                          exact fp32 operation order of oracle/projector_oracle.c (no FMA
+//                          contraction, IEEE divide/sqrt, t += inc) -> first-hit voxel ID image and a
+//                          per-call integer hit histogram.  Pixel -> voxel assignment is bit-exact.
+//   phase 2  k_gather      one 64-lane wavefront per voxel: project the voxel's cube into every
+//                          view (view table staged in LDS), scan the small pixel box in the ID
+//                          image for pixels that first-hit THIS voxel ("occlusion test"), and stream
+//                          their C-wide feature rows from HBM with 16-byte-per-lane coalesced loads,
+//                          accumulating in registers in (view, y, x) order; one non-atomic
+//                          read-modify-write of the output row; hit count by ballot/popcount.
+//                          The box is only a search hint: the per-call histogram of phase 1 is the
+//                          ground truth, and a voxel whose box scan finds fewer pixels than phase 1
+//                          counted is rescanned over the whole image.
+//
+// No float atomics (deterministic sums), no MFMA (the path is gather/accumulate, HBM-bound).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "voxproj.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define VP_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(VP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// optional per-kernel timing (HIP events on the launch stream)
+// ------------------------------------------------------------------------------------------------
+struct Profile {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> pool;   // 4 events per recorded call: start, after prep, after phase 1, after phase 2
+    size_t used = 0;
+    hipEvent_t next()
+    {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+} g_prof;
+
+// ------------------------------------------------------------------------------------------------
+// Parameters shared by the kernels (by value, like the reference's RayCastParams, cudaUtil.h:74-96)
+// ------------------------------------------------------------------------------------------------
+struct Params {
+    int width, height;        // K.cu:403-404
+    float dmin, dmax, inc;    // K.cu:405-407
+    float ox, oy, oz, vs;     // K.cu:412-414
+    int dimz, dimy, dimx;     // K.cu:395-397
+    int B, V, C;
+    long long n_rows;
+};
+
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_WORDS = 64 };
+
+// per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
+struct ViewEntry {
+    float inv[9];   // row-major inverse of the upper-left 3x3 of c2w
+    float pos[3];   // camera position (c2w translation)
+    float ok;       // 1 if the inverse is usable, else 0 (forces whole-image boxes)
+    float pad[3];
+};
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout (all offsets 256-byte aligned; occupancy-derived tables first so that their
+// position does not depend on the image shape -> VP_FLAG_REUSE_ACCEL)
+// ------------------------------------------------------------------------------------------------
+struct Layout {
+    size_t status, cell_of_id, cnt_call, viewtab, hit, total;
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+Layout make_layout(int B, int V, int H, int W, long long n_rows)
+{
+    Layout l;
+    size_t off = 0;
+    l.status = off;      off += align256(ST_WORDS * sizeof(int));
+    l.cell_of_id = off;  off += align256(size_t(B) * size_t(n_rows) * sizeof(int));
+    l.cnt_call = off;    off += align256(size_t(n_rows) * sizeof(int));
+    l.viewtab = off;     off += align256(size_t(B) * V * sizeof(ViewEntry));
+    l.hit = off;         off += align256(size_t(B) * V * H * W * sizeof(int));
+    l.total = off;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers: the arithmetic contract of oracle/projector_oracle.c
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float round_half_away(float x)
+{   // C roundf; x - trunc(x) is exact in binary32
+    float t = truncf(x);
+    float d = fabsf(x - t);
+    return d >= 0.5f ? t + copysignf(1.0f, x) : t;
+}
+
+__device__ __forceinline__ int f2i_sat(float v)
+{   // cvt.rzi.s32.f32 / v_cvt_i32_f32 semantics: saturate, NaN -> 0
+    if (v != v) return 0;
+    v = fminf(fmaxf(v, -2147483648.0f), 2147483520.0f);
+    return (int)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_build_cells: ID -> linear cell index (largest cell wins if an ID labels several cells)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_cells(const long long *__restrict__ occ, int *cell_of_id,
+                                                     long long cells_per_batch, int B, long long n_rows)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    long long total = cells_per_batch * B;
+    for (; i < total; i += stride) {
+        int id = (int)occ[i];   // K.cu:70 long -> int
+        if (id > 0 && id < n_rows) {
+            int b = (int)(i / cells_per_batch);
+            atomicMax(&cell_of_id[(long long)b * n_rows + id], (int)(i - (long long)b * cells_per_batch));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_viewtab: invert each view's 3x3 (double precision) for the phase-2 search boxes
+// ------------------------------------------------------------------------------------------------
+__global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *m = vmi + (long long)i * 16;
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], k = m[10];
+    double A = e * k - f * h, Bc = -(d * k - f * g), Cc = d * h - e * g;
+    double det = a * A + b * Bc + c * Cc;
+    ViewEntry ve;
+    double scale = fabs(a) + fabs(b) + fabs(c) + fabs(d) + fabs(e) + fabs(f) + fabs(g) + fabs(h) + fabs(k);
+    bool ok = (det == det) && fabs(det) > 1e-12 * scale * scale * scale && scale < 1e18;
+    double r = ok ? 1.0 / det : 0.0;
+    ve.inv[0] = (float)(A * r);  ve.inv[1] = (float)(-(b * k - c * h) * r); ve.inv[2] = (float)((b * f - c * e) * r);
+    ve.inv[3] = (float)(Bc * r); ve.inv[4] = (float)((a * k - c * g) * r);  ve.inv[5] = (float)(-(a * f - c * d) * r);
+    ve.inv[6] = (float)(Cc * r); ve.inv[7] = (float)(-(a * h - b * g) * r); ve.inv[8] = (float)((a * e - b * d) * r);
+    ve.pos[0] = m[3]; ve.pos[1] = m[7]; ve.pos[2] = m[11];
+    for (int j = 0; j < 9; j++) ok = ok && (fabsf(ve.inv[j]) < 1e18f);
+    for (int j = 0; j < 3; j++) ok = ok && (fabsf(ve.pos[j]) < 1e18f);
+    ve.ok = ok ? 1.0f : 0.0f;
+    ve.pad[0] = ve.pad[1] = ve.pad[2] = 0.0f;
+    tab[i] = ve;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 1: first-hit ray-march.  One lane per pixel, 8x8 pixel tile per wavefront (coherent rays),
+// 16x16 per workgroup, blockIdx.z = b*V + v.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__ occ,
+                                                   const float *__restrict__ vmi,
+                                                   const float *__restrict__ intr, Params p,
+                                                   int *__restrict__ hit, int *cnt_call, int *status)
+{
+    const int bv = blockIdx.z;
+    const int b = bv / p.V;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (x >= p.width || y >= p.height) return;
+
+    const float *m = vmi + (long long)bv * 16;           // K.cu:178-179 (row-major float4x4)
+    const float fx = intr[b * 4 + 0], fy = intr[b * 4 + 1], mx = intr[b * 4 + 2], my = intr[b * 4 + 3];
+
+    // K.cu:182-184, cudaUtil.h:106-119
+    const float depth = 1.0f * (p.dmax - p.dmin) + p.dmin;
+    const float sx = ((float)(unsigned)x - mx) / fx;
+    const float sy = ((float)(unsigned)y - my) / fy;
+    float cx = depth * sx, cy = depth * sy, cz = depth;
+    float inv = 1.0f / sqrtf(cx * cx + cy * cy + cz * cz);   // cutil_math.h:1207-1211, :81-84
+    const float cdx = cx * inv, cdy = cy * inv, cdz = cz * inv;
+    // K.cu:185 float4x4 * float3 (w = 1), cuda_SimpleMatrixUtil.h:900-908
+    const float cpx = m[0] * 0.0f + m[1] * 0.0f + m[2] * 0.0f + m[3] * 1.0f;
+    const float cpy = m[4] * 0.0f + m[5] * 0.0f + m[6] * 0.0f + m[7] * 1.0f;
+    const float cpz = m[8] * 0.0f + m[9] * 0.0f + m[10] * 0.0f + m[11] * 1.0f;
+    // K.cu:186-187 float4x4 * float4(camDir, 0), cuda_SimpleMatrixUtil.h:888-896
+    float wx = m[0] * cdx + m[1] * cdy + m[2] * cdz + m[3] * 0.0f;
+    float wy = m[4] * cdx + m[5] * cdy + m[6] * cdz + m[7] * 0.0f;
+    float wz = m[8] * cdx + m[9] * cdy + m[10] * cdz + m[11] * 0.0f;
+    inv = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);
+    const float wdx = wx * inv, wdy = wy * inv, wdz = wz * inv;
+
+    // K.cu:31-82
+    const float d2r = 1.0f / cdz;
+    float t = d2r * p.dmin;
+    const float tEnd = d2r * p.dmax;
+    const long long *occ_b = occ + (long long)b * p.dimz * p.dimy * p.dimx;
+    const float fw = (float)p.width, fh = (float)p.height;
+    int id = 0;
+    while (t < tEnd) {
+        const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
+        const int ix = f2i_sat(round_half_away((px - p.ox) / p.vs));
+        const int iy = f2i_sat(round_half_away((py - p.oy) / p.vs));
+        const int iz = f2i_sat(round_half_away((pz - p.oz) / p.vs));
+        const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
+        const float u = fx * (camx / camz) + mx;
+        const float v = fy * (camy / camz) + my;
+        const bool inb = (u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh);
+        if (inb && ix >= 0 && iy >= 0 && iz >= 0 && ix < p.dimx && iy < p.dimy && iz < p.dimz) {
+            id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
+            if (id != 0) break;
+        }
+        t += p.inc;
+    }
+    if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
+        atomicOr(&status[ST_BADID], 1);
+        id = 0;
+    }
+    hit[((long long)bv * p.height + y) * p.width + x] = id;
+    if (id != 0) atomicAdd(&cnt_call[id], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase 2: one wavefront per voxel
+// ------------------------------------------------------------------------------------------------
+template <int K, int VEC>
+struct Acc {
+    float a[K * VEC];
+};
+
+// Scan the pixel box [x0,x1]x[y0,y1] of one view's ID image for pixels whose first hit is `id`, in
+// raster order, and add their feature rows (channels cb .. cb+64*K*VEC) to acc.  64 lanes cover a
+// tile of tw x (64/tw) pixels, tw = smallest power of two >= box width (capped at 64), so tiles
+// and the lanes inside a tile are visited in raster order.
+template <int K, int VEC, int U>
+__device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int *__restrict__ hv,
+                                         int W, int C, int id, int x0, int y0, int x1, int y1,
+                                         int cb, int lane, Acc<K, VEC> &acc, int &found)
+{
+    const int bw = x1 - x0 + 1;
+    const int lg = bw >= 64 ? 6 : (bw <= 1 ? 0 : 32 - __builtin_clz(bw - 1));
+    const int tw = 1 << lg, th = 64 >> lg;
+    const int lx = lane & (tw - 1), ly = lane >> lg;
+    for (int ty = y0; ty <= y1; ty += th) {
+        const int py = ty + ly;
+        for (int tx = x0; tx <= x1; tx += tw) {
+            const int px = tx + lx;
+            const bool inb = (px <= x1) && (py <= y1);
+            const int pix = py * W + px;
+            const int h = inb ? hv[pix] : 0;
+            unsigned long long m = __ballot(h == id);
+            found += __popcll(m);
+            while (m) {
+                int n = 0;
+                long long off[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    off[j] = 0;
+                    if (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        off[j] = (long long)__builtin_amdgcn_readlane(pix, l) * C + cb;
+                        n = j + 1;
+                    }
+                }
+                if constexpr (VEC == 4) {
+                    float4 r[U][K];
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                const int ch = (k * 64 + lane) * 4;
+                                r[j][k] = (cb + ch < C)
+                                              ? *reinterpret_cast<const float4 *>(fv + off[j] + ch)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                acc.a[k * 4 + 0] += r[j][k].x;
+                                acc.a[k * 4 + 1] += r[j][k].y;
+                                acc.a[k * 4 + 2] += r[j][k].z;
+                                acc.a[k * 4 + 3] += r[j][k].w;
+                            }
+                        }
+                } else {
+                    float r[U][K];
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                const int ch = k * 64 + lane;
+                                r[j][k] = (cb + ch < C) ? fv[off[j] + ch] : 0.f;
+                            }
+                        }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) acc.a[k] += r[j][k];
+                        }
+                }
+            }
+        }
+    }
+}
+
+// Conservative pixel box of voxel cube (centre c, half edge h) in view ve; returns false if empty.
+__device__ __forceinline__ bool voxel_box(const ViewEntry &ve, float fx, float fy, float mx, float my,
+                                          float cxw, float cyw, float czw, float h, int W, int H,
+                                          int &x0, int &y0, int &x1, int &y1)
+{
+    x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
+    if (ve.ok == 0.0f) return true;
+    const float dx = cxw - ve.pos[0], dy = cyw - ve.pos[1], dz = czw - ve.pos[2];
+    const float camx = ve.inv[0] * dx + ve.inv[1] * dy + ve.inv[2] * dz;
+    const float camy = ve.inv[3] * dx + ve.inv[4] * dy + ve.inv[5] * dz;
+    const float camz = ve.inv[6] * dx + ve.inv[7] * dy + ve.inv[8] * dz;
+    const float ez = h * (fabsf(ve.inv[6]) + fabsf(ve.inv[7]) + fabsf(ve.inv[8]));
+    if (!(camz + ez > 0.0f)) return false;                 // cube entirely behind the camera plane
+    if (!(camz - ez > 1e-4f * (fabsf(camz) + ez))) return true;   // straddles the plane: whole image
+    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const float a = (s & 1) ? h : -h, b = (s & 2) ? h : -h, c = (s & 4) ? h : -h;
+        const float qx = camx + ve.inv[0] * a + ve.inv[1] * b + ve.inv[2] * c;
+        const float qy = camy + ve.inv[3] * a + ve.inv[4] * b + ve.inv[5] * c;
+        const float qz = camz + ve.inv[6] * a + ve.inv[7] * b + ve.inv[8] * c;
+        const float u = fx * (qx / qz) + mx, v = fy * (qy / qz) + my;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+    if (!(umin == umin) || !(umax == umax) || !(vmin == vmin) || !(vmax == vmax)) return true;
+    const float fW = (float)W, fH = (float)H;
+    if (umax < -2.0f || vmax < -2.0f || umin > fW + 1.0f || vmin > fH + 1.0f) return false;
+    x0 = max(0, (int)floorf(fmaxf(umin, 0.0f)) - 1);
+    y0 = max(0, (int)floorf(fmaxf(vmin, 0.0f)) - 1);
+    x1 = min(W - 1, (int)ceilf(fminf(umax, fW)) + 1);
+    y1 = min(H - 1, (int)ceilf(fminf(vmax, fH)) + 1);
+    return x0 <= x1 && y0 <= y1;
+}
+
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(256) void k_gather(const float *__restrict__ feats,
+                                                const int *__restrict__ hit,
+                                                const ViewEntry *__restrict__ viewtab,
+                                                const float *__restrict__ intr,
+                                                const int *__restrict__ cell_of_id,
+                                                const int *__restrict__ cnt_call, Params p,
+                                                int *count, float *out, int *status)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long idl = wid + 1;
+    if (idl >= p.n_rows) return;
+    const int id = (int)idl;
+    const int expected = cnt_call[id];
+    if (expected == 0) return;
+
+    const int W = p.width, H = p.height, C = p.C;
+    const long long HW = (long long)H * W;
+    const float hh = 0.5f * fabsf(p.vs) * 1.02f + 1e-6f * (fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(p.vs) * (p.dimx + p.dimy + p.dimz));
+    const int CB = 64 * K * VEC;
+
+    for (int cb = 0; cb < C; cb += CB) {
+        Acc<K, VEC> acc;
+        float *orow = out + (long long)id * C + cb;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if constexpr (VEC == 4) {
+                const int ch = (k * 64 + lane) * 4;
+                float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
+            } else {
+                const int ch = k * 64 + lane;
+                acc.a[k] = (cb + ch < C) ? orow[ch] : 0.f;
+            }
+        }
+        Acc<K, VEC> acc0 = acc;
+        int found = 0;
+        for (int b = 0; b < p.B && found < expected; b++) {
+            const int cell = cell_of_id[(long long)b * p.n_rows + id];
+            if (cell < 0) continue;
+            const int czi = cell / (p.dimy * p.dimx);
+            const int rem = cell - czi * (p.dimy * p.dimx);
+            const int cyi = rem / p.dimx, cxi = rem - cyi * p.dimx;
+            const float cxw = p.ox + (float)cxi * p.vs, cyw = p.oy + (float)cyi * p.vs, czw = p.oz + (float)czi * p.vs;
+            const float fx = intr[b * 4 + 0], fy = intr[b * 4 + 1], mx = intr[b * 4 + 2], my = intr[b * 4 + 3];
+            for (int vbase = 0; vbase < p.V && found < expected; vbase += 64) {
+                const int v = vbase + lane;
+                int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+                bool ne = false;
+                if (v < p.V) ne = voxel_box(viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, W, H, x0, y0, x1, y1);
+                unsigned long long vm = __ballot(ne);
+                while (vm && found < expected) {
+                    const int l = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
+                    const long long bv = (long long)b * p.V + vbase + l;
+                    scan_box<K, VEC, U>(feats + bv * HW * C, hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
+                }
+            }
+        }
+        if (found != expected) {
+            // the search boxes missed pixels (an ID labelling several cells, a degenerate pose...):
+            // redo this voxel over whole images.  Correctness never depends on the boxes.
+            if (lane == 0 && cb == 0) atomicAdd(&status[ST_BOXMISS], 1);
+            acc = acc0;
+            found = 0;
+            for (long long bv = 0; bv < (long long)p.B * p.V; bv++)
+                scan_box<K, VEC, U>(feats + bv * HW * C, hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if constexpr (VEC == 4) {
+                const int ch = (k * 64 + lane) * 4;
+                if (cb + ch < C)
+                    *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+            } else {
+                const int ch = k * 64 + lane;
+                if (cb + ch < C) orow[ch] = acc.a[k];
+            }
+        }
+        if (cb == 0 && lane == 0) count[id] += found;   // K.cu:77 (one add of the per-call total)
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int vp_abi_version(void) { return VP_ABI_VERSION; }
+
+const char *vp_last_error(void) { return g_err; }
+
+size_t vp_workspace_bytes(int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows)
+{
+    (void)C; (void)dimz; (void)dimy; (void)dimx;
+    if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || n_rows <= 0) return 0;
+    return make_layout(B, V, H, W, n_rows).total;
+}
+
+int vp_project_features(const float *feats, const int64_t *occ, const float *vmi, const float *intr,
+                        const float *opts_host, int32_t *count, float *out,
+                        const float *grid_origin_host, float voxel_size,
+                        int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows,
+                        void *workspace, size_t workspace_bytes, void *stream_, int flags)
+{
+    if (!feats || !occ || !vmi || !intr || !opts_host || !count || !out || !grid_origin_host || !workspace)
+        return fail(VP_EINVAL, "null pointer argument");
+    if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || C <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0 || n_rows <= 0)
+        return fail(VP_EINVAL, "non-positive dimension");
+    if ((long long)B * V > 65535) return fail(VP_EINVAL, "B*V = %lld exceeds 65535", (long long)B * V);
+    if ((long long)dimz * dimy * dimx >= (1ll << 31)) return fail(VP_EINVAL, "occupancy grid has >= 2^31 cells per batch");
+    if ((long long)H * W >= (1ll << 31) || n_rows >= (1ll << 31)) return fail(VP_EINVAL, "image or row count >= 2^31");
+    Params p;
+    p.width = (int)(opts_host[0] + 0.5f);    // K.cu:403
+    p.height = (int)(opts_host[1] + 0.5f);   // K.cu:404
+    if (p.width != W || p.height != H)
+        return fail(VP_EINVAL, "opts width/height (%d,%d) must equal the feature map's (%d,%d)", p.width, p.height, W, H);
+    p.dmin = opts_host[2]; p.dmax = opts_host[3]; p.inc = opts_host[4];
+    if (!(p.inc > 0.0f)) return fail(VP_EINVAL, "rayIncrement must be > 0 (the reference would never terminate)");
+    p.ox = grid_origin_host[0]; p.oy = grid_origin_host[1]; p.oz = grid_origin_host[2];
+    p.vs = voxel_size;
+    p.dimz = dimz; p.dimy = dimy; p.dimx = dimx;
+    p.B = B; p.V = V; p.C = C; p.n_rows = n_rows;
+
+    const Layout l = make_layout(B, V, H, W, n_rows);
+    if (workspace_bytes < l.total) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, l.total);
+    if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
+    char *ws = (char *)workspace;
+    int *status = (int *)(ws + l.status);
+    int *cell_of_id = (int *)(ws + l.cell_of_id);
+    int *cnt_call = (int *)(ws + l.cnt_call);
+    ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab);
+    int *hit = (int *)(ws + l.hit);
+    hipStream_t stream = (hipStream_t)stream_;
+
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        if (g_prof.on) {
+            prof = true;
+            for (int i = 0; i < 4; i++) prof = prof && ((ev[i] = g_prof.next()) != nullptr);
+        }
+    }
+    if (prof) VP_HIP(hipEventRecord(ev[0], stream));
+    VP_HIP(hipMemsetAsync(status, 0, ST_WORDS * sizeof(int), stream));
+    VP_HIP(hipMemsetAsync(cnt_call, 0, size_t(n_rows) * sizeof(int), stream));
+    if (!(flags & VP_FLAG_REUSE_ACCEL)) {
+        VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), stream));
+        const long long cells = (long long)dimz * dimy * dimx;
+        const int blocks = (int)((cells * B + 255) / 256 > 8192 ? 8192 : (cells * B + 255) / 256);
+        hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, stream,
+                           (const long long *)occ, cell_of_id, cells, B, (long long)n_rows);
+    }
+    hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, stream, vmi, viewtab, B * V);
+    if (prof) VP_HIP(hipEventRecord(ev[1], stream));
+    hipLaunchKernelGGL(k_first_hit, dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, stream,
+                       (const long long *)occ, vmi, intr, p, hit, cnt_call, status);
+    if (prof) VP_HIP(hipEventRecord(ev[2], stream));
+    const int blocks2 = (int)((n_rows - 1 + 3) / 4);
+    if (blocks2 > 0) {
+        const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
+#define LAUNCH_GATHER(K, VEC, U)                                                                          \
+    hipLaunchKernelGGL((k_gather<K, VEC, U>), dim3(blocks2), dim3(256), 0, stream, feats, hit, viewtab,    \
+                       intr, cell_of_id, cnt_call, p, count, out, status)
+        if (vec_ok && C > 256) LAUNCH_GATHER(2, 4, 4);
+        else if (vec_ok) LAUNCH_GATHER(1, 4, 4);
+        else LAUNCH_GATHER(4, 1, 4);
+#undef LAUNCH_GATHER
+    }
+    if (prof) VP_HIP(hipEventRecord(ev[3], stream));
+    VP_HIP(hipGetLastError());
+    if (flags & VP_FLAG_SYNC) return vp_workspace_status(workspace, stream_);
+    return VP_OK;
+}
+
+int vp_workspace_status(void *workspace, void *stream_)
+{
+    if (!workspace) return fail(VP_EINVAL, "null workspace");
+    hipStream_t stream = (hipStream_t)stream_;
+    int st[ST_WORDS];
+    VP_HIP(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream));
+    VP_HIP(hipStreamSynchronize(stream));
+    if (st[ST_BADID])
+        return fail(VP_EBADID, "a ray hit an occupancy ID outside [1, n_rows): outputs are too small for the grid's IDs");
+    return VP_OK;
+}
+
+int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream_)
+{
+    if (!workspace || !host_words || n <= 0 || n > ST_WORDS) return fail(VP_EINVAL, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    VP_HIP(hipMemcpyAsync(host_words, workspace, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    VP_HIP(hipStreamSynchronize(stream));
+    return VP_OK;
+}
+
+int vp_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> g(g_prof.mu);
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    return VP_OK;
+}
+
+int vp_profile_read(double *ms3, int64_t *calls)
+{
+    if (!ms3 || !calls) return fail(VP_EINVAL, "null pointer argument");
+    std::lock_guard<std::mutex> g(g_prof.mu);
+    ms3[0] = ms3[1] = ms3[2] = 0.0;
+    const size_t n = g_prof.used / 4;
+    for (size_t i = 0; i < n; i++) {
+        VP_HIP(hipEventSynchronize(g_prof.pool[i * 4 + 3]));
+        for (int k = 0; k < 3; k++) {
+            float ms = 0.f;
+            VP_HIP(hipEventElapsedTime(&ms, g_prof.pool[i * 4 + k], g_prof.pool[i * 4 + k + 1]));
+            ms3[k] += ms;
+        }
+    }
+    *calls = (int64_t)n;
+    g_prof.used = 0;
+    return VP_OK;
+}
+
+int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, int W, int C,
+                      int dimz, int dimy, int dimx, int64_t n_rows, void *stream_)
+{
+    (void)C; (void)dimz; (void)dimy; (void)dimx;
+    if (!workspace || !dst) return fail(VP_EINVAL, "null pointer argument");
+    const Layout l = make_layout(B, V, H, W, n_rows);
+    VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + l.hit, size_t(B) * V * H * W * sizeof(int),
+                          hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    return VP_OK;
+}
+
+}  // extern "C"

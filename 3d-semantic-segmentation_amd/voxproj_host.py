@@ -1,0 +1,181 @@
+"""ctypes binding of libvoxproj.so (the C-ABI declared in include/voxproj.h) plus workspace plumbing.
+
+PyTorch is used only for device memory and streams.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible, the product entry points raise.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvoxproj.so")
+
+VP_OK = 0
+VP_FLAG_SYNC = 1
+VP_FLAG_REUSE_ACCEL = 2
+
+_lib = None
+_lock = threading.Lock()
+
+EXPORTS = [
+    "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
+    "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
+    "vp_profile_enable", "vp_profile_read",
+]
+
+
+class VoxprojError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libvoxproj.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc", "voxproj.hip")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "voxproj.h")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (dlopen only; no device call is made here)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise VoxprojError(
+                    f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                    "(there is no CPU fallback)")
+            L = ctypes.CDLL(LIB_PATH)
+            L.vp_abi_version.restype = ctypes.c_int
+            L.vp_last_error.restype = ctypes.c_char_p
+            L.vp_workspace_bytes.restype = ctypes.c_size_t
+            L.vp_workspace_bytes.argtypes = [ctypes.c_int] * 8 + [ctypes.c_int64]
+            vp = ctypes.c_void_p
+            L.vp_project_features.restype = ctypes.c_int
+            L.vp_project_features.argtypes = [
+                vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), vp, vp, ctypes.POINTER(ctypes.c_float),
+                ctypes.c_float] + [ctypes.c_int] * 8 + [ctypes.c_int64, vp, ctypes.c_size_t, vp, ctypes.c_int]
+            L.vp_workspace_status.restype = ctypes.c_int
+            L.vp_workspace_status.argtypes = [vp, vp]
+            L.vp_workspace_counters.restype = ctypes.c_int
+            L.vp_workspace_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, vp]
+            L.vp_copy_hit_image.restype = ctypes.c_int
+            L.vp_copy_hit_image.argtypes = [vp, vp] + [ctypes.c_int] * 8 + [ctypes.c_int64, vp]
+            L.vp_profile_enable.restype = ctypes.c_int
+            L.vp_profile_enable.argtypes = [ctypes.c_int]
+            L.vp_profile_read.restype = ctypes.c_int
+            L.vp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+            _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().vp_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != VP_OK:
+        raise VoxprojError(f"voxproj error {rc}: {last_error()}")
+
+
+def workspace_bytes(B, V, H, W, C, dimz, dimy, dimx, n_rows):
+    return int(lib().vp_workspace_bytes(B, V, H, W, C, dimz, dimy, dimx, n_rows))
+
+
+class Workspace:
+    """Grow-only device scratch buffer (one per device), allocated through torch's allocator."""
+
+    def __init__(self):
+        self.buf = None
+        self.accel_key = None
+
+    def ensure(self, nbytes, device):
+        import torch
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+            self.accel_key = None
+        ptr = self.buf.data_ptr()
+        return (ptr + 255) & ~255
+
+
+_workspaces = {}
+
+
+def get_workspace(device):
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = Workspace()
+    return ws
+
+
+def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
+                         workspace=None, sync=True, reuse_accel=None):
+    """Call vp_project_features on torch CUDA tensors (already validated by the caller).
+
+    opts5 / grid_origin3 are python sequences of floats.  Returns the Workspace used.
+    ``reuse_accel``: None = decide from (occ.data_ptr(), occ._version, shape, n_rows) of the previous
+    call on this workspace; True/False = force.
+    """
+    import torch
+    B, V, H, W, C = feats.shape
+    _, dimz, dimy, dimx = occ.shape
+    n_rows = int(count.shape[0])
+    ws = workspace if workspace is not None else get_workspace(feats.device)
+    need = workspace_bytes(B, V, H, W, C, dimz, dimy, dimx, n_rows)
+    ptr = ws.ensure(need, feats.device)
+    key = (occ.data_ptr(), occ._version, tuple(occ.shape), n_rows, B)
+    if reuse_accel is None:
+        reuse_accel = (ws.accel_key == key) and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1"
+    flags = (VP_FLAG_SYNC if sync else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
+    o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
+    g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
+    stream = torch.cuda.current_stream(feats.device).cuda_stream
+    with torch.cuda.device(feats.device):
+        rc = lib().vp_project_features(
+            feats.data_ptr(), occ.data_ptr(), vmi.data_ptr(), intr.data_ptr(), o,
+            count.data_ptr(), out.data_ptr(), g, ctypes.c_float(float(voxel_size)),
+            B, V, H, W, C, dimz, dimy, dimx, n_rows, ptr, need, stream, flags)
+    if rc != VP_OK:
+        ws.accel_key = None
+        check(rc)
+    ws.accel_key = key
+    ws.last_shape = (B, V, H, W, C, dimz, dimy, dimx, n_rows)
+    return ws
+
+
+def hit_image(ws, device):
+    """First-hit ID image of the last call on ``ws`` as an int32 [B,V,H,W] tensor (test hook)."""
+    import torch
+    B, V, H, W, C, dimz, dimy, dimx, n_rows = ws.last_shape
+    dst = torch.empty((B, V, H, W), dtype=torch.int32, device=device)
+    ptr = (ws.buf.data_ptr() + 255) & ~255
+    stream = torch.cuda.current_stream(device).cuda_stream
+    check(lib().vp_copy_hit_image(ptr, dst.data_ptr(), B, V, H, W, C, dimz, dimy, dimx, n_rows, stream))
+    torch.cuda.current_stream(device).synchronize()
+    return dst
+
+
+def counters(ws, device):
+    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss)."""
+    import torch
+    arr = (ctypes.c_int32 * 8)()
+    ptr = (ws.buf.data_ptr() + 255) & ~255
+    stream = torch.cuda.current_stream(device).cuda_stream
+    check(lib().vp_workspace_counters(ptr, arr, 8, stream))
+    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]))
+
+
+def profile_enable(on=True):
+    check(lib().vp_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """dict(prep_ms, first_hit_ms, gather_ms, calls): summed HIP-event times since the last read."""
+    ms = (ctypes.c_double * 3)()
+    calls = ctypes.c_int64(0)
+    check(lib().vp_profile_read(ms, ctypes.byref(calls)))
+    return dict(prep_ms=ms[0], first_hit_ms=ms[1], gather_ms=ms[2], calls=int(calls.value))

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxel-views/s + achieved HBM GB/s of the 2D -> sparse-voxel feature projector.
+
+Workload (BASELINE.json metric config, "R2"): 200 000 occupied voxels x 300 views x 968x548x512 fp32
+synthetic feature maps (SURVEY.md section 8d generator, seed 0).  One STEP = one pass of the hot path
+over the whole scene: every view's feature map is read from HBM exactly once, in calls of --chunk views
+through the C-ABI (vp_project_features), features already resident in HBM.  326 GB of feature maps do
+not fit one GPU, so a pool of --pool distinct maps (default 32 = 34.8 GB) is cycled; the rays, the
+voxel assignment and the bytes moved are those of 300 distinct views.
+
+Multi-GPU (torchrun, one rank per GPU): rank r projects views r::G of the same 300-view scene, then one
+RCCL all-reduce of the per-voxel {feature-sum f32 [N+1,512], hit-count i32 [N+1]} -- total work fixed,
+"scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" for the dominant kernel
+(k_gather, HBM-bound; HIP events on its launch stream, recorded live during the timed steps) and
+"cpu_baseline" (the CPU oracle -- a port of the reference kernel -- timed on this box's host cores on a
+bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "3d-semantic-segmentation_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (n_vox, n_views, W, H, C)
+    "R2": (200000, 300, 968, 548, 512),      # BASELINE config 3 (metric config)
+    "R1": (80000, 100, 484, 274, 512),       # BASELINE config 2
+    "S0": (10000, 8, 64, 64, 32),            # BASELINE config 1 (plumbing)
+}
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="R2", choices=sorted(WORKLOADS))
+    ap.add_argument("--chunk", type=int, default=4, help="views per vp_project_features call")
+    ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
+    ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=2, help="views in the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, C, n_views, n_threads):
+    """Time the CPU oracle (port of project_image_cuda_kernel.cu:24-92,157-187) on n_views views."""
+    from oracle import oracle
+    from synthetic_scene import make_features_np
+    feats = make_features_np(n_views, scene.height, scene.width, C, seed=0)[None]
+    n_rows = scene.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    occ = scene.occ[None].astype(np.int64)
+    t0 = time.perf_counter()
+    oracle.project_features(feats, occ, scene.c2w[:n_views].reshape(-1), scene.intr[None], scene.opts(),
+                            scene.grid_origin, scene.voxel_size, count, out, want_hits=False, nthreads=n_threads)
+    dt = time.perf_counter() - t0
+    return dict(value=scene.n_vox * n_views / dt / 1e6, unit="Mvoxel-views/s", cores=n_threads, kind="port",
+                sample=f"{n_views} of the workload's views at full resolution, all {scene.n_vox} voxels, "
+                       f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices)")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the projector has no CPU fallback")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import voxproj_host
+    from synthetic_scene import make_features_torch, make_scene
+
+    n_vox, n_views, W, H, C = WORKLOADS[a.workload]
+    if a.views:
+        n_views = a.views
+    scene = make_scene(n_vox, n_views, W, H, seed=0)
+    my_views = list(range(rank, n_views, world))
+    chunk = max(1, min(a.chunk, len(my_views)))
+    pool = max(chunk, (min(a.pool, len(my_views)) // chunk) * chunk)
+
+    feats = torch.empty((1, pool, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(pool, H, W, C, dev, seed=0, out=feats[0])
+    occ = torch.from_numpy(scene.occ[None].astype(np.int64)).to(dev)
+    c2w = torch.from_numpy(scene.c2w).to(dev)
+    intr = torch.from_numpy(scene.intr[None]).to(dev)
+    n_rows = n_vox + 1
+    count = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out = torch.zeros(n_rows, C, dtype=torch.float32, device=dev)
+    opts = [float(v) for v in scene.opts()]
+    origin = [float(v) for v in scene.grid_origin]
+    ws = voxproj_host.Workspace()
+
+    # calls of one step: (pool slot of the first view, view indices)
+    calls = []
+    for i in range(0, len(my_views), chunk):
+        vs = my_views[i:i + chunk]
+        slot = (i % pool) if (i % pool) + len(vs) <= pool else 0
+        calls.append((slot, vs))
+    vmis = [c2w[vs].reshape(-1).contiguous() for _, vs in calls]
+
+    def one_call(ci, sync=False):
+        slot, vs = calls[ci]
+        voxproj_host.project_features_raw(feats[:, slot:slot + len(vs)], occ, vmis[ci], intr, opts, count, out,
+                                          origin, scene.voxel_size, workspace=ws, sync=sync,
+                                          reuse_accel=(ci > 0 or None))
+
+    def step():
+        count.zero_()
+        out.zero_()
+        for ci in range(len(calls)):
+            one_call(ci)
+        if dist is not None:
+            dist.all_reduce(out)
+            dist.all_reduce(count)
+
+    # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
+    hit_px, touched, gather_bytes = 0, 0, 0
+    for ci in range(len(calls)):
+        count.zero_()
+        one_call(ci, sync=True)
+        ph, nt = int(count.sum().item()), int((count > 0).sum().item())
+        hit_px += ph
+        touched += nt
+        gather_bytes += ph * C * 4 + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
+    cnt = voxproj_host.counters(ws, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    voxproj_host.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = voxproj_host.profile_read()
+    voxproj_host.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = n_vox * n_views / (dt / a.steps) / 1e6
+        launches = max(prof["calls"], 1)
+        gather_ms = prof["gather_ms"] / launches
+        ach = (gather_bytes / len(calls)) / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
+        # whole-path algorithmic bytes per step: feature rows + output RMW + counts + ID image w+r
+        algo_step = hit_px * C * 4 + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
+        res = {
+            "metric": "Mvoxel-views/sec", "value": round(value, 3), "unit": "Mvoxel-views/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} fp32 feature maps, "
+                                   f"room-shell scene seed 0, dmin 0.01 dmax 10 step 0.5*voxel",
+                       "views_per_call": chunk, "resident_feature_maps": pool,
+                       "parallelism": f"views r::{world} per GPU + one RCCL all-reduce of sum/count" if world > 1 else "single GPU"},
+            "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
+            "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
+                                  "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
+                                  "gather": round(prof["gather_ms"] / a.steps, 3)},
+            "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"],
+            "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
+        }
+        if not a.no_cpu_baseline:
+            ncores = os.cpu_count() or 1
+            res["cpu_baseline"] = cpu_baseline(scene, C, min(a.cpu_views, n_views), ncores)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/*
+ * voxproj.h -- C-ABI of the MI355X-native 2D -> sparse-voxel feature projector.
+ *
+ * Plain pointers and sizes only (no torch types).  Every entry point names the reference
+ * interface it replaces; paths are relative to
+ * /root/reference/cuda_project_image_to_sparse_voxel/ :
+ *
+ *   K.cu  = project_image_cuda_kernel.cu      W.cpp = project_image_cuda.cpp
+ *   DPF   = debug_project_features.py         DPC   = debug_project_colors.py
+ *   BSO   = build_sparse_occupancy.py         AGG   = aggregate_voxel_features_onthefly.py
+ *
+ * All device pointers must belong to the HIP device that is current on the calling thread.
+ * Functions return VP_OK (0) or a negative VP_E* code; vp_last_error() gives the message for
+ * the calling thread.  Nothing here falls back to a CPU path.
+ */
+#ifndef VOXPROJ_H
+#define VOXPROJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP_ABI_VERSION 1
+
+enum {
+    VP_OK = 0,
+    VP_EINVAL = -1,      /* bad argument (shape, null pointer, size)                             */
+    VP_EWORKSPACE = -2,  /* workspace too small / misaligned                                     */
+    VP_EHIP = -3,        /* a HIP runtime call failed                                            */
+    VP_EBADID = -4,      /* an occupancy ID hit by a ray is outside [1, n_rows)  (K.cu:71,77:     */
+                         /* the reference would write out of bounds)                 */
+    VP_EUNSUPPORTED = -5 /* pred_mode = true (K.cu:444-450 is unreachable in the reference too)  */
+};
+
+/* flags for vp_project_features */
+enum {
+    VP_FLAG_SYNC = 1,        /* block until the device work is done and report device-side errors
+                                (the reference always does: K.cu:454-457)                          */
+    VP_FLAG_REUSE_ACCEL = 2  /* the occupancy-derived tables in the workspace are still valid for
+                                this occupancy grid (same pointer, contents and n_rows): skip
+                                rebuilding them                                                    */
+};
+
+int vp_abi_version(void);
+const char *vp_last_error(void);
+
+/*
+ * Bytes of device scratch memory vp_project_features needs for a call of this shape
+ * (first-hit ID image, per-call hit histogram, ID -> cell table, view table).
+ */
+size_t vp_workspace_bytes(int B, int V, int H, int W, int C,
+                          int dimz, int dimy, int dimx, int64_t n_rows);
+
+/*
+ * Replaces project_features_cuda_forward_impl (K.cu:374-459), i.e. what the extension function
+ * project_features_cuda.project_features_cuda(...) (W.cpp:23-79) does after validation, for
+ * pred_mode = false.
+ *
+ *   feats        f32 [B,V,H,W,C] channels-last, device            (K.cu:375)
+ *   occ          i64 [B,dimz,dimy,dimx], 0 = empty, else voxel ID  (K.cu:376)
+ *   vmi          f32 [B*V*16] row-major camera->world matrices     (K.cu:377, :178-179)
+ *   intr         f32 [B,4] = fx, fy, mx, my per batch              (K.cu:378, cudaUtil.h:86-93)
+ *   opts_host    f32 [5] HOST = width, height, depthMin, depthMax, rayIncrement (K.cu:400-407)
+ *   count        i32 [n_rows]   in/out, count[id] += #pixels        (K.cu:77)
+ *   out          f32 [n_rows,C] in/out, out[id,:] += feature rows   (K.cu:85-91)
+ *   grid_origin_host f32 [3] HOST                                  (K.cu:412-413)
+ *   voxel_size                                                     (K.cu:414)
+ *   workspace    device scratch of >= vp_workspace_bytes(...) bytes, 256-byte aligned
+ *   stream       hipStream_t (NULL = default stream)
+ *
+ * Results: first-hit voxel assignment and counts bit-exact with the arithmetic contract in
+ * oracle/projector_oracle.c; feature sums accumulated in fp32 in (b, v, y, x) order per voxel.
+ * width/height in opts must equal W/H (the reference indexes features with the opts values,
+ * K.cu:74-76; a mismatch reads garbage there and is rejected here).
+ */
+int vp_project_features(const float *feats, const int64_t *occ, const float *vmi,
+                        const float *intr, const float *opts_host,
+                        int32_t *count, float *out,
+                        const float *grid_origin_host, float voxel_size,
+                        int B, int V, int H, int W, int C,
+                        int dimz, int dimy, int dimx, int64_t n_rows,
+                        void *workspace, size_t workspace_bytes,
+                        void *stream, int flags);
+
+/*
+ * Reads back and clears the device-side status word of a workspace after the stream has been
+ * synchronised by the caller (for calls made without VP_FLAG_SYNC).  Returns VP_OK, VP_EBADID...
+ */
+int vp_workspace_status(void *workspace, void *stream);
+
+/*
+ * Diagnostic counters of the last call on this workspace, copied to host_words[0..n) after a
+ * stream synchronise: [0] = rays that hit an out-of-range ID, [1] = voxels whose search box
+ * missed pixels and were rescanned over whole images (performance hint only; results are exact
+ * either way).  No reference counterpart.
+ */
+int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream);
+
+/*
+ * Per-kernel device timing with HIP events recorded on the stream the kernels are launched on
+ * (measurement harness; no reference counterpart -- the reference has no timers).
+ * vp_profile_enable(1) starts recording for subsequent vp_project_features calls of this process;
+ * vp_profile_read synchronises the recorded events, returns the summed milliseconds of
+ * ms[0] = table preparation (memsets, ID->cell table, view table), ms[1] = k_first_hit (phase 1),
+ * ms[2] = k_gather (phase 2) and the number of calls, then clears the record.
+ */
+int vp_profile_enable(int on);
+int vp_profile_read(double *ms3, int64_t *calls);
+
+/*
+ * Copies the first-hit ID image i32 [B,V,H,W] of the LAST vp_project_features call on this
+ * workspace into dst (device pointer).  Test/diagnostic hook: the reference has no such output,
+ * the parity tests use it to compare the pixel -> voxel assignment of K.cu:47-82 directly.
+ */
+int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, int W,
+                      int C, int dimz, int dimy, int dimx, int64_t n_rows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXPROJ_H */

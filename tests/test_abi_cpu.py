@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/voxproj.h declares, and the extension-module mirror validates like the reference wrapper
+(project_image_cuda.cpp:38-61).  No compute call is made here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "voxproj.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vp_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import voxproj_host
+    voxproj_host.build()
+    lib = ctypes.CDLL(voxproj_host.LIB_PATH)
+    names = _declared_functions()
+    assert "vp_project_features" in names and len(names) >= 6
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(voxproj_host.EXPORTS) == names
+    lib.vp_abi_version.restype = ctypes.c_int
+    assert lib.vp_abi_version() == 1
+
+
+def test_workspace_bytes_is_pure_host_arithmetic():
+    import voxproj_host
+    n = voxproj_host.workspace_bytes(1, 2, 48, 64, 16, 10, 20, 30, 1001)
+    assert n >= 2 * 48 * 64 * 4 + 2 * 1001 * 4 and n % 256 == 0
+    assert voxproj_host.workspace_bytes(0, 2, 48, 64, 16, 10, 20, 30, 1001) == 0
+
+
+def _args(device="cpu"):
+    B, V, H, W, C = 1, 1, 4, 4, 8
+    return [torch.zeros(B, V, H, W, C, device=device), torch.zeros(B, 2, 2, 2, dtype=torch.int64, device=device),
+            torch.eye(4, device=device).reshape(-1), torch.ones(B, 4, device=device),
+            torch.tensor([W, H, 0.01, 10.0, 0.5]), torch.zeros(3, dtype=torch.int32, device=device),
+            torch.zeros(3, C, device=device), torch.tensor([False]), torch.zeros(3), 1.0]
+
+
+def test_wrapper_rejects_cpu_tensors_like_check_cuda():
+    import project_features_cuda as m
+    with pytest.raises(RuntimeError, match="encoded_2d_features must be a CUDA tensor"):
+        m.project_features_cuda(*_args())
+
+
+def test_wrapper_signature_is_ten_positional_arguments():
+    import inspect
+
+    import project_features_cuda as m
+    params = list(inspect.signature(m.project_features_cuda).parameters)
+    assert params == ["encoded_2d_features", "occupancy_3D", "viewMatrixInv", "intrinsicParams", "opts",
+                      "mapping2dto3d_num", "projected_features", "pred_mode_t", "grid_origin", "voxel_size"]
