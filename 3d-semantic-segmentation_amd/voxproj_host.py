@@ -7,6 +7,7 @@ import ctypes
 import os
 import subprocess
 import threading
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvoxproj.so")
@@ -90,7 +91,7 @@ class Workspace:
 
     def __init__(self):
         self.buf = None
-        self.accel_key = None
+        self.accel_key = None     # (weakref to the occupancy tensor, its _version, shape, n_rows)
 
     def ensure(self, nbytes, device):
         import torch
@@ -117,8 +118,10 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     """Call vp_project_features on torch CUDA tensors (already validated by the caller).
 
     opts5 / grid_origin3 are python sequences of floats.  Returns the Workspace used.
-    ``reuse_accel``: None = decide from (occ.data_ptr(), occ._version, shape, n_rows) of the previous
-    call on this workspace; True/False = force.
+    ``reuse_accel``: None = reuse the occupancy-derived tables only if ``occ`` is the very same (still
+    alive) tensor object as in the previous call on this workspace, with an unchanged torch version
+    counter -- a data_ptr match alone is not enough, the caching allocator hands freed addresses out
+    again; True/False = force.
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -127,9 +130,11 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     ws = workspace if workspace is not None else get_workspace(feats.device)
     need = workspace_bytes(B, V, H, W, C, dimz, dimy, dimx, n_rows)
     ptr = ws.ensure(need, feats.device)
-    key = (occ.data_ptr(), occ._version, tuple(occ.shape), n_rows, B)
+    key = (occ._version, occ.data_ptr(), tuple(occ.shape), n_rows)
     if reuse_accel is None:
-        reuse_accel = (ws.accel_key == key) and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1"
+        prev = ws.accel_key
+        reuse_accel = (prev is not None and prev[0]() is occ and prev[1] == key
+                       and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1")
     flags = (VP_FLAG_SYNC if sync else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
@@ -142,7 +147,7 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     if rc != VP_OK:
         ws.accel_key = None
         check(rc)
-    ws.accel_key = key
+    ws.accel_key = (weakref.ref(occ), key)
     ws.last_shape = (B, V, H, W, C, dimz, dimy, dimx, n_rows)
     return ws
 

@@ -216,8 +216,9 @@ def test_full_resolution_view_properties(oracle_mod):
     # checksum of checksums: total over voxels == total over hit pixels (float64)
     mask = (flat > 0)
     tot_px = feats.reshape(-1, C)[mask].double().sum(0)
+    tot_abs = feats.reshape(-1, C)[mask].double().abs().sum(0)
     tot_vx = out_t.double().sum(0)
-    assert torch.allclose(tot_px, tot_vx, rtol=1e-6, atol=1e-6)
+    assert ((tot_px - tot_vx).abs() <= 1e-6 * tot_abs).all()      # fp32 row sums: ~1e-7 relative each
     # exact per-voxel sums for a sample of voxels, in raster order
     ids = torch.unique(flat[mask])[:: 997][:40]
     f2 = feats.reshape(-1, C)
@@ -230,4 +231,4 @@ def test_full_resolution_view_properties(oracle_mod):
     # idempotence of the accumulate contract: a second call doubles counts and (to rounding) sums
     m.project_features_cuda(*args)
     assert torch.equal(count_t.long(), 2 * torch.bincount(flat, minlength=n_rows) * (torch.arange(n_rows, device=DEV) > 0))
-    assert torch.allclose(out_t.double().sum(0), 2 * tot_px, rtol=1e-6, atol=1e-6)
+    assert ((out_t.double().sum(0) - 2 * tot_px).abs() <= 2e-6 * tot_abs).all()
