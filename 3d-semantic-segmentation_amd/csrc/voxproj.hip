@@ -100,17 +100,24 @@ struct ViewEntry {
 // position does not depend on the image shape -> VP_FLAG_REUSE_ACCEL)
 // ------------------------------------------------------------------------------------------------
 struct Layout {
-    size_t status, cell_of_id, cnt_call, viewtab, hit, total;
+    size_t status, cell_of_id, mask64, dist, dist_tmp, cnt_call, viewtab, hit, total;
+    int nbx, nby, nbz;
+    long long nblk;   // occupancy blocks (4x4x4 cells) per batch
 };
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-Layout make_layout(int B, int V, int H, int W, long long n_rows)
+Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int dimy, int dimx)
 {
     Layout l;
     size_t off = 0;
+    l.nbx = (dimx + 3) / 4; l.nby = (dimy + 3) / 4; l.nbz = (dimz + 3) / 4;
+    l.nblk = (long long)l.nbx * l.nby * l.nbz;
     l.status = off;      off += align256(ST_WORDS * sizeof(int));
     l.cell_of_id = off;  off += align256(size_t(B) * size_t(n_rows) * sizeof(int));
+    l.mask64 = off;      off += align256(size_t(B) * l.nblk * sizeof(unsigned long long));
+    l.dist = off;        off += align256(size_t(B) * l.nblk);
+    l.dist_tmp = off;    off += align256(size_t(B) * l.nblk);
     l.cnt_call = off;    off += align256(size_t(n_rows) * sizeof(int));
     l.viewtab = off;     off += align256(size_t(B) * V * sizeof(ViewEntry));
     l.hit = off;         off += align256(size_t(B) * V * H * W * sizeof(int));
@@ -136,21 +143,59 @@ __device__ __forceinline__ int f2i_sat(float v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_build_cells: ID -> linear cell index (largest cell wins if an ID labels several cells)
+// occupancy-derived tables (built once per occupancy grid, see VP_FLAG_REUSE_ACCEL):
+//   cell_of_id[b][id]   linear cell index of voxel `id` (largest cell wins if an ID labels several)
+//   mask64[b][blk]      one bit per cell of each 4x4x4 block: (int)occ != 0   (bit = z%4*16+y%4*4+x%4)
+//   dist[b][blk]        Chebyshev distance, in blocks, to the nearest non-empty block (0 = non-empty,
+//                       capped at 255) -- a lower bound that lets the march leap over empty space
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_cells(const long long *__restrict__ occ, int *cell_of_id,
-                                                     long long cells_per_batch, int B, long long n_rows)
+                                                     unsigned long long *mask64,
+                                                     int dimz, int dimy, int dimx, int nby, int nbx,
+                                                     long long nblk, int B, long long n_rows)
 {
+    const long long cells_per_batch = (long long)dimz * dimy * dimx;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    long long total = cells_per_batch * B;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long total = cells_per_batch * B;
     for (; i < total; i += stride) {
-        int id = (int)occ[i];   // K.cu:70 long -> int
-        if (id > 0 && id < n_rows) {
-            int b = (int)(i / cells_per_batch);
-            atomicMax(&cell_of_id[(long long)b * n_rows + id], (int)(i - (long long)b * cells_per_batch));
-        }
+        const int id = (int)occ[i];   // K.cu:70 long -> int
+        if (id == 0) continue;
+        const int b = (int)(i / cells_per_batch);
+        const int cell = (int)(i - (long long)b * cells_per_batch);
+        const int z = cell / (dimy * dimx), r = cell - z * (dimy * dimx), y = r / dimx, x = r - y * dimx;
+        const long long blk = ((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
+        const int bit = ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
+        atomicOr(&mask64[(long long)b * nblk + blk], 1ull << bit);
+        if (id > 0 && id < n_rows) atomicMax(&cell_of_id[(long long)b * n_rows + id], cell);
     }
+}
+
+// Separable Chebyshev distance transform on the block grid: D = min_q max(|dx|,|dy|,|dz|) factors into
+// three 1-D passes because max distributes over min.  axis 0: along x from the masks; 1: y; 2: z.
+__global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__restrict__ mask64,
+                                                    const unsigned char *__restrict__ src,
+                                                    unsigned char *__restrict__ dst,
+                                                    int nbz, int nby, int nbx, int B, int axis)
+{
+    const long long nblk = (long long)nbz * nby * nbx;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk * B) return;
+    const long long base = (i / nblk) * nblk;
+    const int blk = (int)(i - base);
+    const int z = blk / (nby * nbx), r = blk - z * (nby * nbx), y = r / nbx, x = r - y * nbx;
+    int best = 255;
+    if (axis == 0) {
+        for (int q = 0; q < nbx; q++)
+            if (mask64[base + ((long long)z * nby + y) * nbx + q] != 0ull) best = min(best, abs(x - q));
+    } else if (axis == 1) {
+        for (int q = 0; q < nby; q++)
+            best = min(best, max(abs(y - q), (int)src[base + ((long long)z * nby + q) * nbx + x]));
+    } else {
+        for (int q = 0; q < nbz; q++)
+            best = min(best, max(abs(z - q), (int)src[base + ((long long)q * nby + y) * nbx + x]));
+    }
+    dst[i] = (unsigned char)best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,10 +227,28 @@ __global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
 // ------------------------------------------------------------------------------------------------
 // phase 1: first-hit ray-march.  One lane per pixel, 8x8 pixel tile per wavefront (coherent rays),
 // 16x16 per workgroup, blockIdx.z = b*V + v.
+//
+// ACCEL = false: the reference loop, one occupancy probe per step (K.cu:47-82), kept as the A/B arm.
+// ACCEL = true : the same sample sequence t_k (repeated fp32 addition, never t0 + k*inc), but
+//   * samples that provably cannot land in an occupied cell are not evaluated: from the block
+//     distance field, a sample in cell c with D = (lower bound on the Chebyshev distance, in cells,
+//     from c to the nearest occupied cell) allows skipping J steps with 1.5 + J*dcell <= D, where
+//     dcell bounds the per-step motion in cells (1% + fp slack, see DESIGN.md for the proof);
+//   * the cell index roundf((p - origin)/vs) is taken from the product with 1/vs when that product is
+//     farther than 2^-21*|q| from a rounding boundary (then both roundings agree), and from the IEEE
+//     division otherwise;
+//   * occupancy comes from a 64-bit block mask held in registers while the ray stays in a 4x4x4 block;
+//   * the (u,v) bounds test of K.cu:53-61 is evaluated, with the reference's exact operations, only
+//     for samples that found an occupied cell (it gates nothing else).
+// Every evaluated sample uses the reference's exact fp32 operations, so the first-hit ID is identical.
 // ------------------------------------------------------------------------------------------------
+template <bool ACCEL>
 __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__ occ,
                                                    const float *__restrict__ vmi,
                                                    const float *__restrict__ intr, Params p,
+                                                   const unsigned long long *__restrict__ mask64,
+                                                   const unsigned char *__restrict__ dist,
+                                                   int nby, int nbx, long long nblk,
                                                    int *__restrict__ hit, int *cnt_call, int *status)
 {
     const int bv = blockIdx.z;
@@ -220,23 +283,96 @@ __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__
     const float d2r = 1.0f / cdz;
     float t = d2r * p.dmin;
     const float tEnd = d2r * p.dmax;
-    const long long *occ_b = occ + (long long)b * p.dimz * p.dimy * p.dimx;
+    const long long cells = (long long)p.dimz * p.dimy * p.dimx;
+    const long long *occ_b = occ + (long long)b * cells;
     const float fw = (float)p.width, fh = (float)p.height;
     int id = 0;
-    while (t < tEnd) {
-        const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
-        const int ix = f2i_sat(round_half_away((px - p.ox) / p.vs));
-        const int iy = f2i_sat(round_half_away((py - p.oy) / p.vs));
-        const int iz = f2i_sat(round_half_away((pz - p.oz) / p.vs));
-        const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
-        const float u = fx * (camx / camz) + mx;
-        const float v = fy * (camy / camz) + my;
-        const bool inb = (u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh);
-        if (inb && ix >= 0 && iy >= 0 && iz >= 0 && ix < p.dimx && iy < p.dimy && iz < p.dimz) {
-            id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
-            if (id != 0) break;
+    if constexpr (!ACCEL) {
+        while (t < tEnd) {
+            const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
+            const int ix = f2i_sat(round_half_away((px - p.ox) / p.vs));
+            const int iy = f2i_sat(round_half_away((py - p.oy) / p.vs));
+            const int iz = f2i_sat(round_half_away((pz - p.oz) / p.vs));
+            const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
+            const float u = fx * (camx / camz) + mx;
+            const float v = fy * (camy / camz) + my;
+            const bool inb = (u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh);
+            if (inb && ix >= 0 && iy >= 0 && iz >= 0 && ix < p.dimx && iy < p.dimy && iz < p.dimz) {
+                id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
+                if (id != 0) break;
+            }
+            t += p.inc;
         }
-        t += p.inc;
+    } else {
+        const unsigned long long *mask_b = mask64 + (long long)b * nblk;
+        const unsigned char *dist_b = dist + (long long)b * nblk;
+        const float rvs = 1.0f / p.vs;
+        // upper bound of the per-step motion in cells (1% covers the rounding of t += inc and of rvs)
+        const float dcell = fabsf(p.inc * rvs) * fmaxf(fabsf(wdx), fmaxf(fabsf(wdy), fabsf(wdz))) * 1.01f + 1e-6f;
+        // leaping is allowed only where fp32 position error stays far below one cell and the step count
+        // is sane; otherwise every sample is evaluated (still exact, just slower)
+        const float span = (fabsf(cpx) + fabsf(cpy) + fabsf(cpz) + fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(tEnd)) * fabsf(rvs);
+        const bool leap_ok = (span < 131072.0f) && (fabsf(tEnd) < 1.0e5f * fabsf(p.inc)) && (dcell == dcell) && (dcell < 1.0e6f);
+        const float inv_dcell = leap_ok ? 0.999f / dcell : 0.0f;
+        int cur_blk = -1, cur_d = 0;
+        unsigned long long cur_mask = 0ull;
+        while (t < tEnd) {
+            const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
+            const float ax = px - p.ox, ay = py - p.oy, az = pz - p.oz;
+            const float qx = ax * rvs, qy = ay * rvs, qz = az * rvs;
+            const float rx = rintf(qx), ry = rintf(qy), rz = rintf(qz);
+            const bool safe = (fabsf(qx - rx) < __builtin_fmaf(fabsf(qx), -0x1p-21f, 0.5f)) &&
+                              (fabsf(qy - ry) < __builtin_fmaf(fabsf(qy), -0x1p-21f, 0.5f)) &&
+                              (fabsf(qz - rz) < __builtin_fmaf(fabsf(qz), -0x1p-21f, 0.5f));
+            int ix, iy, iz;
+            if (safe) {   // |q| < 2^20 here, conversions are exact
+                ix = (int)rx; iy = (int)ry; iz = (int)rz;
+            } else {
+                ix = f2i_sat(round_half_away(ax / p.vs));
+                iy = f2i_sat(round_half_away(ay / p.vs));
+                iz = f2i_sat(round_half_away(az / p.vs));
+            }
+            int D = 0;   // lower bound on the Chebyshev cell distance from (ix,iy,iz) to an occupied cell
+            if ((unsigned)ix < (unsigned)p.dimx && (unsigned)iy < (unsigned)p.dimy && (unsigned)iz < (unsigned)p.dimz) {
+                const int blk = ((iz >> 2) * nby + (iy >> 2)) * nbx + (ix >> 2);
+                if (blk != cur_blk) {
+                    cur_blk = blk;
+                    cur_d = dist_b[blk];
+                    if (cur_d == 0) cur_mask = mask_b[blk];
+                }
+                if (cur_d == 0) {
+                    const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
+                    if ((cur_mask >> bit) & 1ull) {
+                        const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
+                        const float u = fx * (camx / camz) + mx;
+                        const float v = fy * (camy / camz) + my;
+                        if ((u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh)) {
+                            id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
+                            if (id != 0) break;
+                        }
+                    }
+                } else {
+                    D = (cur_d - 1) * 4 + 1;
+                }
+            } else if (leap_ok) {
+                const int lim = 1 << 29;
+                const int jx = min(max(ix, -lim), lim), jy = min(max(iy, -lim), lim), jz = min(max(iz, -lim), lim);
+                const int ex = jx < 0 ? -jx : (jx >= p.dimx ? jx - p.dimx + 1 : 0);
+                const int ey = jy < 0 ? -jy : (jy >= p.dimy ? jy - p.dimy + 1 : 0);
+                const int ez = jz < 0 ? -jz : (jz >= p.dimz ? jz - p.dimz + 1 : 0);
+                const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
+                const int kx = min(max(jx, 0), p.dimx - 1), ky = min(max(jy, 0), p.dimy - 1), kz = min(max(jz, 0), p.dimz - 1);
+                const int dd = dist_b[((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2)];
+                const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
+                D = max(dbox, din - dbox);
+            }
+            t += p.inc;
+            if (D >= 2) {
+                int J = (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f);
+                for (; J >= 4 && t < tEnd; J -= 4) { t += p.inc; t += p.inc; t += p.inc; t += p.inc; }
+                for (; J > 0 && t < tEnd; J--) t += p.inc;
+            }
+        }
     }
     if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
         atomicOr(&status[ST_BADID], 1);
@@ -470,9 +606,9 @@ const char *vp_last_error(void) { return g_err; }
 
 size_t vp_workspace_bytes(int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows)
 {
-    (void)C; (void)dimz; (void)dimy; (void)dimx;
-    if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || n_rows <= 0) return 0;
-    return make_layout(B, V, H, W, n_rows).total;
+    (void)C;
+    if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || n_rows <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0) return 0;
+    return make_layout(B, V, H, W, n_rows, dimz, dimy, dimx).total;
 }
 
 int vp_project_features(const float *feats, const int64_t *occ, const float *vmi, const float *intr,
@@ -500,12 +636,15 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     p.dimz = dimz; p.dimy = dimy; p.dimx = dimx;
     p.B = B; p.V = V; p.C = C; p.n_rows = n_rows;
 
-    const Layout l = make_layout(B, V, H, W, n_rows);
+    const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx);
     if (workspace_bytes < l.total) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, l.total);
     if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
     char *ws = (char *)workspace;
     int *status = (int *)(ws + l.status);
     int *cell_of_id = (int *)(ws + l.cell_of_id);
+    unsigned long long *mask64 = (unsigned long long *)(ws + l.mask64);
+    unsigned char *dist = (unsigned char *)(ws + l.dist);
+    unsigned char *dist_tmp = (unsigned char *)(ws + l.dist_tmp);
     int *cnt_call = (int *)(ws + l.cnt_call);
     ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab);
     int *hit = (int *)(ws + l.hit);
@@ -525,15 +664,24 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     VP_HIP(hipMemsetAsync(cnt_call, 0, size_t(n_rows) * sizeof(int), stream));
     if (!(flags & VP_FLAG_REUSE_ACCEL)) {
         VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), stream));
+        VP_HIP(hipMemsetAsync(mask64, 0, size_t(B) * l.nblk * sizeof(unsigned long long), stream));
         const long long cells = (long long)dimz * dimy * dimx;
-        const int blocks = (int)((cells * B + 255) / 256 > 8192 ? 8192 : (cells * B + 255) / 256);
-        hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, stream,
-                           (const long long *)occ, cell_of_id, cells, B, (long long)n_rows);
+        const int blocks = (int)((cells * B + 255) / 256 > 16384 ? 16384 : (cells * B + 255) / 256);
+        hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, stream, (const long long *)occ, cell_of_id,
+                           mask64, dimz, dimy, dimx, l.nby, l.nbx, l.nblk, B, (long long)n_rows);
+        const int db = (int)((l.nblk * B + 255) / 256);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, stream, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, B, 0);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, stream, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, B, 1);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, stream, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, B, 2);
     }
     hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, stream, vmi, viewtab, B * V);
     if (prof) VP_HIP(hipEventRecord(ev[1], stream));
-    hipLaunchKernelGGL(k_first_hit, dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, stream,
-                       (const long long *)occ, vmi, intr, p, hit, cnt_call, status);
+    if (flags & VP_FLAG_EXACT_MARCH)
+        hipLaunchKernelGGL(k_first_hit<false>, dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, stream,
+                           (const long long *)occ, vmi, intr, p, mask64, dist, l.nby, l.nbx, l.nblk, hit, cnt_call, status);
+    else
+        hipLaunchKernelGGL(k_first_hit<true>, dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, stream,
+                           (const long long *)occ, vmi, intr, p, mask64, dist, l.nby, l.nbx, l.nblk, hit, cnt_call, status);
     if (prof) VP_HIP(hipEventRecord(ev[2], stream));
     const int blocks2 = (int)((n_rows - 1 + 3) / 4);
     if (blocks2 > 0) {
@@ -603,9 +751,9 @@ int vp_profile_read(double *ms3, int64_t *calls)
 int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, int W, int C,
                       int dimz, int dimy, int dimx, int64_t n_rows, void *stream_)
 {
-    (void)C; (void)dimz; (void)dimy; (void)dimx;
+    (void)C;
     if (!workspace || !dst) return fail(VP_EINVAL, "null pointer argument");
-    const Layout l = make_layout(B, V, H, W, n_rows);
+    const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx);
     VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + l.hit, size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
     return VP_OK;

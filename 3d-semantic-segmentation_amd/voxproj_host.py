@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libvoxproj.so")
 VP_OK = 0
 VP_FLAG_SYNC = 1
 VP_FLAG_REUSE_ACCEL = 2
+VP_FLAG_EXACT_MARCH = 4
 
 _lib = None
 _lock = threading.Lock()
@@ -114,14 +115,15 @@ def get_workspace(device):
 
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
-                         workspace=None, sync=True, reuse_accel=None):
+                         workspace=None, sync=True, reuse_accel=None, exact_march=None):
     """Call vp_project_features on torch CUDA tensors (already validated by the caller).
 
     opts5 / grid_origin3 are python sequences of floats.  Returns the Workspace used.
     ``reuse_accel``: None = reuse the occupancy-derived tables only if ``occ`` is the very same (still
     alive) tensor object as in the previous call on this workspace, with an unchanged torch version
     counter -- a data_ptr match alone is not enough, the caching allocator hands freed addresses out
-    again; True/False = force.
+    again; True/False = force.  ``exact_march``: evaluate every ray sample (A/B arm of the leaping march;
+    default from env VOXPROJ_EXACT_MARCH).
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -135,7 +137,10 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
         prev = ws.accel_key
         reuse_accel = (prev is not None and prev[0]() is occ and prev[1] == key
                        and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1")
-    flags = (VP_FLAG_SYNC if sync else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
+    if exact_march is None:
+        exact_march = os.environ.get("VOXPROJ_EXACT_MARCH", "0") == "1"
+    flags = ((VP_FLAG_SYNC if sync else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
+             | (VP_FLAG_EXACT_MARCH if exact_march else 0))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream

@@ -39,9 +39,11 @@ enum {
 enum {
     VP_FLAG_SYNC = 1,        /* block until the device work is done and report device-side errors
                                 (the reference always does: K.cu:454-457)                          */
-    VP_FLAG_REUSE_ACCEL = 2  /* the occupancy-derived tables in the workspace are still valid for
+    VP_FLAG_REUSE_ACCEL = 2, /* the occupancy-derived tables in the workspace are still valid for
                                 this occupancy grid (same pointer, contents and n_rows): skip
                                 rebuilding them                                                    */
+    VP_FLAG_EXACT_MARCH = 4  /* A/B arm: evaluate every ray sample like K.cu:47-82 does instead of
+                                leaping over provably empty space (same results, slower)           */
 };
 
 int vp_abi_version(void);
@@ -49,7 +51,8 @@ const char *vp_last_error(void);
 
 /*
  * Bytes of device scratch memory vp_project_features needs for a call of this shape
- * (first-hit ID image, per-call hit histogram, ID -> cell table, view table).
+ * (first-hit ID image, per-call hit histogram, ID -> cell table, occupancy block masks and block
+ * distance field, view table).
  */
 size_t vp_workspace_bytes(int B, int V, int H, int W, int C,
                           int dimz, int dimy, int dimx, int64_t n_rows);
