@@ -27,6 +27,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -60,18 +61,76 @@ int fail(int code, const char *fmt, ...)
 struct Profile {
     std::mutex mu;
     bool on = false;
-    std::vector<hipEvent_t> pool;   // 4 events per recorded call: start, after prep, after phase 1, after phase 2
-    size_t used = 0;
-    hipEvent_t next()
+    std::vector<hipEvent_t> pool;    // event pairs
+    std::vector<int> kind;           // per pair: 0 prep, 1 first_hit, 2 gather, 3 heavy
+    size_t used = 0;                 // pairs in use
+    // returns the pair index, or -1
+    int next(int k)
     {
-        if (used == pool.size()) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            pool.push_back(e);
+        if (used * 2 == pool.size()) {
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+            pool.push_back(e0); pool.push_back(e1); kind.push_back(0);
         }
-        return pool[used++];
+        kind[used] = k;
+        return (int)used++;
     }
 } g_prof;
+
+// RAII-less helper: times [begin, end) of one kernel group on `stream` when profiling is on
+struct ProfSpan {
+    int idx = -1;
+    hipStream_t stream = nullptr;
+    void begin(int k, hipStream_t s)
+    {
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        if (!g_prof.on) return;
+        idx = g_prof.next(k);
+        stream = s;
+        if (idx >= 0) (void)hipEventRecord(g_prof.pool[idx * 2], s);
+    }
+    void end()
+    {
+        if (idx < 0) return;
+        std::lock_guard<std::mutex> g(g_prof.mu);
+        (void)hipEventRecord(g_prof.pool[idx * 2 + 1], stream);
+        idx = -1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// side stream + events for VP_FLAG_PIPELINE, one state per workspace pointer
+// ------------------------------------------------------------------------------------------------
+struct PipeState {
+    hipStream_t side = nullptr;
+    hipEvent_t fh_done[2] = {nullptr, nullptr};      // phase 1 of buffer set q finished (side stream)
+    hipEvent_t heavy_done[2] = {nullptr, nullptr};   // heavy-voxel kernel of set q finished (side stream)
+    hipEvent_t call_done[2] = {nullptr, nullptr};    // everything of the call that used set q finished (caller's stream)
+    hipEvent_t entry = nullptr;                      // caller's stream position at call entry
+    bool used[2] = {false, false};
+    long long calls = 0;
+    int last_q = 0;
+};
+std::mutex g_pipe_mu;
+std::vector<std::pair<void *, PipeState *>> g_pipes;
+
+PipeState *pipe_state(void *workspace, bool create)
+{
+    std::lock_guard<std::mutex> g(g_pipe_mu);
+    for (auto &kv : g_pipes)
+        if (kv.first == workspace) return kv.second;
+    if (!create) return nullptr;
+    PipeState *ps = new PipeState();
+    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess;
+    for (int q = 0; q < 2 && ok; q++)
+        ok = hipEventCreateWithFlags(&ps->fh_done[q], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ps->heavy_done[q], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ps->call_done[q], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ps->entry, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete ps; return nullptr; }
+    g_pipes.emplace_back(workspace, ps);
+    return ps;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Parameters shared by the kernels (by value, like the reference's RayCastParams, cudaUtil.h:74-96)
@@ -85,7 +144,7 @@ struct Params {
     long long n_rows;
 };
 
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_WORDS = 64 };
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
@@ -100,7 +159,9 @@ struct ViewEntry {
 // position does not depend on the image shape -> VP_FLAG_REUSE_ACCEL)
 // ------------------------------------------------------------------------------------------------
 struct Layout {
-    size_t status, cell_of_id, mask64, dist, dist_tmp, cnt_call, viewtab, hit, total;
+    size_t cell_of_id, mask64, dist, dist_tmp;           // occupancy-derived tables (shared)
+    size_t status[2], cnt_call[2], heavy[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
+    size_t total;
     int nbx, nby, nbz;
     long long nblk;   // occupancy blocks (4x4x4 cells) per batch
 };
@@ -113,14 +174,21 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
     size_t off = 0;
     l.nbx = (dimx + 3) / 4; l.nby = (dimy + 3) / 4; l.nbz = (dimz + 3) / 4;
     l.nblk = (long long)l.nbx * l.nby * l.nbz;
-    l.status = off;      off += align256(ST_WORDS * sizeof(int));
+    // status words of set 0 come first: vp_workspace_status/counters read the head of the workspace
+    l.status[0] = off;   off += align256(ST_WORDS * sizeof(int));
+    l.status[1] = off;   off += align256(ST_WORDS * sizeof(int));
     l.cell_of_id = off;  off += align256(size_t(B) * size_t(n_rows) * sizeof(int));
     l.mask64 = off;      off += align256(size_t(B) * l.nblk * sizeof(unsigned long long));
     l.dist = off;        off += align256(size_t(B) * l.nblk);
     l.dist_tmp = off;    off += align256(size_t(B) * l.nblk);
-    l.cnt_call = off;    off += align256(size_t(n_rows) * sizeof(int));
-    l.viewtab = off;     off += align256(size_t(B) * V * sizeof(ViewEntry));
-    l.hit = off;         off += align256(size_t(B) * V * H * W * sizeof(int));
+    for (int q = 0; q < 2; q++) {
+        l.cnt_call[q] = off; off += align256(size_t(n_rows) * sizeof(int));
+        l.heavy[q] = off;    off += align256(size_t(n_rows) * sizeof(int));
+        l.viewtab[q] = off;  off += align256(size_t(B) * V * sizeof(ViewEntry));
+    }
+    for (int q = 0; q < 2; q++) {
+        l.hit[q] = off;      off += align256(size_t(B) * V * H * W * sizeof(int));
+    }
     l.total = off;
     return l;
 }
@@ -249,7 +317,8 @@ __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__
                                                    const unsigned long long *__restrict__ mask64,
                                                    const unsigned char *__restrict__ dist,
                                                    int nby, int nbx, long long nblk,
-                                                   int *__restrict__ hit, int *cnt_call, int *status)
+                                                   int *__restrict__ hit, int *cnt_call, int *heavy_list,
+                                                   int heavy_t, int *status)
 {
     const int bv = blockIdx.z;
     const int b = bv / p.V;
@@ -379,7 +448,10 @@ __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__
         id = 0;
     }
     hit[((long long)bv * p.height + y) * p.width + x] = id;
-    if (id != 0) atomicAdd(&cnt_call[id], 1);
+    if (id != 0) {
+        // the pixel that lifts a voxel's per-call count above heavy_t enlists it for the heavy role
+        if (atomicAdd(&cnt_call[id], 1) == heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = id;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,9 +544,12 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
     }
 }
 
-// Conservative pixel box of voxel cube (centre c, half edge h) in view ve; returns false if empty.
+// Conservative pixel box of a voxel cube (centre c, half edge h) in view ve; returns false if empty.
+// Every ray sample has camera depth >= depthMin (t >= depthMin/camDir.z, K.cu:31-32), so the cube is
+// clipped against the plane z = zn = 0.98*depthMin before it is projected: vertices in front of the
+// plane are projected as they are, edges crossing it contribute their intersection point.
 __device__ __forceinline__ bool voxel_box(const ViewEntry &ve, float fx, float fy, float mx, float my,
-                                          float cxw, float cyw, float czw, float h, int W, int H,
+                                          float cxw, float cyw, float czw, float h, float zn, int W, int H,
                                           int &x0, int &y0, int &x1, int &y1)
 {
     x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
@@ -484,20 +559,44 @@ __device__ __forceinline__ bool voxel_box(const ViewEntry &ve, float fx, float f
     const float camy = ve.inv[3] * dx + ve.inv[4] * dy + ve.inv[5] * dz;
     const float camz = ve.inv[6] * dx + ve.inv[7] * dy + ve.inv[8] * dz;
     const float ez = h * (fabsf(ve.inv[6]) + fabsf(ve.inv[7]) + fabsf(ve.inv[8]));
-    if (!(camz + ez > 0.0f)) return false;                 // cube entirely behind the camera plane
-    if (!(camz - ez > 1e-4f * (fabsf(camz) + ez))) return true;   // straddles the plane: whole image
+    if (!(camz + ez > zn)) return false;                   // cube entirely nearer than any sample
     float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    float qx[8], qy[8], qz[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const float a = (s & 1) ? h : -h, b = (s & 2) ? h : -h, c = (s & 4) ? h : -h;
-        const float qx = camx + ve.inv[0] * a + ve.inv[1] * b + ve.inv[2] * c;
-        const float qy = camy + ve.inv[3] * a + ve.inv[4] * b + ve.inv[5] * c;
-        const float qz = camz + ve.inv[6] * a + ve.inv[7] * b + ve.inv[8] * c;
-        const float u = fx * (qx / qz) + mx, v = fy * (qy / qz) + my;
-        umin = fminf(umin, u); umax = fmaxf(umax, u);
-        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        qx[s] = camx + ve.inv[0] * a + ve.inv[1] * b + ve.inv[2] * c;
+        qy[s] = camy + ve.inv[3] * a + ve.inv[4] * b + ve.inv[5] * c;
+        qz[s] = camz + ve.inv[6] * a + ve.inv[7] * b + ve.inv[8] * c;
+        if (qz[s] >= zn) {
+            const float u = fx * (qx[s] / qz[s]) + mx, v = fy * (qy[s] / qz[s]) + my;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        }
+    }
+    if (!(camz - ez >= zn)) {
+        // some vertices are behind the plane: add the 12 edges' crossings with z = zn
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                const int o = s ^ (1 << ax);
+                if (o < s) continue;
+                const bool fs = qz[s] >= zn, fo = qz[o] >= zn;
+                if (fs == fo) continue;
+                const float tt = (zn - qz[s]) / (qz[o] - qz[s]);
+                const float ix = qx[s] + tt * (qx[o] - qx[s]), iy = qy[s] + tt * (qy[o] - qy[s]);
+                const float u = fx * (ix / zn) + mx, v = fy * (iy / zn) + my;
+                umin = fminf(umin, u); umax = fmaxf(umax, u);
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            }
+        }
+        // crossing points are computed with cancellation: widen by 2 % of the box and 2 px
+        const float pu = 0.02f * (umax - umin) + 2.0f, pv = 0.02f * (vmax - vmin) + 2.0f;
+        umin -= pu; umax += pu; vmin -= pv; vmax += pv;
     }
     if (!(umin == umin) || !(umax == umax) || !(vmin == vmin) || !(vmax == vmax)) return true;
+    if (!(umin <= umax) || !(vmin <= vmax)) return true;   // nothing in front although the depth test passed
     const float fW = (float)W, fH = (float)H;
     if (umax < -2.0f || vmax < -2.0f || umin > fW + 1.0f || vmin > fH + 1.0f) return false;
     x0 = max(0, (int)floorf(fmaxf(umin, 0.0f)) - 1);
@@ -507,57 +606,107 @@ __device__ __forceinline__ bool voxel_box(const ViewEntry &ve, float fx, float f
     return x0 <= x1 && y0 <= y1;
 }
 
-template <int K, int VEC, int U>
-__global__ __launch_bounds__(256) void k_gather(const float *__restrict__ feats,
-                                                const int *__restrict__ hit,
-                                                const ViewEntry *__restrict__ viewtab,
-                                                const float *__restrict__ intr,
-                                                const int *__restrict__ cell_of_id,
-                                                const int *__restrict__ cnt_call, Params p,
-                                                int *count, float *out, int *status)
-{
-    const int lane = threadIdx.x & 63;
-    const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long idl = wid + 1;
-    if (idl >= p.n_rows) return;
-    const int id = (int)idl;
-    const int expected = cnt_call[id];
-    if (expected == 0) return;
+struct GatherArgs {
+    const float *feats;
+    const int *hit;
+    const ViewEntry *viewtab;
+    const float *intr;
+    const int *cell_of_id;
+    const int *cnt_call;
+    const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
+    const int *n_heavy;
+    int heavy_t;
+    int *count;
+    float *out;
+    int *status;
+};
 
+constexpr int GW = 16;   // wavefronts per k_gather_heavy workgroup
+
+template <int K, int VEC>
+__device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, int cb, int C, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if constexpr (VEC == 4) {
+            const int ch = (k * 64 + lane) * 4;
+            const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
+        } else {
+            const int ch = k * 64 + lane;
+            acc.a[k] = (cb + ch < C) ? orow[ch] : 0.f;
+        }
+    }
+}
+
+template <int K, int VEC>
+__device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, int cb, int C, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if constexpr (VEC == 4) {
+            const int ch = (k * 64 + lane) * 4;
+            if (cb + ch < C)
+                *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+        } else {
+            const int ch = k * 64 + lane;
+            if (cb + ch < C) orow[ch] = acc.a[k];
+        }
+    }
+}
+
+// world-space centre of voxel `id` in batch b; false if the grid of batch b does not hold the ID
+__device__ __forceinline__ bool voxel_centre(const GatherArgs &g, const Params &p, int b, int id,
+                                             float &cxw, float &cyw, float &czw)
+{
+    const int cell = g.cell_of_id[(long long)b * p.n_rows + id];
+    if (cell < 0) return false;
+    const int czi = cell / (p.dimy * p.dimx);
+    const int rem = cell - czi * (p.dimy * p.dimx);
+    const int cyi = rem / p.dimx, cxi = rem - cyi * p.dimx;
+    cxw = p.ox + (float)cxi * p.vs; cyw = p.oy + (float)cyi * p.vs; czw = p.oz + (float)czi * p.vs;
+    return true;
+}
+
+__device__ __forceinline__ float box_half_edge(const Params &p)
+{
+    return 0.5f * fabsf(p.vs) * 1.02f +
+           1e-6f * (fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(p.vs) * (p.dimx + p.dimy + p.dimz));
+}
+
+// camera depth below which no ray sample exists (t starts at depthMin/camDir.z); a non-positive or
+// non-finite depthMin degrades to a tiny positive plane (boxes grow, results stay exact)
+__device__ __forceinline__ float near_plane(const Params &p)
+{
+    const float zn = 0.98f * p.dmin;
+    return (zn > 1e-6f && zn < 1e30f) ? zn : 1e-6f;
+}
+
+// Normal role: one wavefront sums all pixels of one voxel, in (b, v, y, x) order, starting from the
+// row already in `out` -- bit-identical to the oracle's serial accumulation.
+template <int K, int VEC, int U>
+__device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Params &p, int id, int expected, int lane)
+{
     const int W = p.width, H = p.height, C = p.C;
     const long long HW = (long long)H * W;
-    const float hh = 0.5f * fabsf(p.vs) * 1.02f + 1e-6f * (fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(p.vs) * (p.dimx + p.dimy + p.dimz));
-    const int CB = 64 * K * VEC;
-
+    const float hh = box_half_edge(p);
+    const float zn = near_plane(p);
+    constexpr int CB = 64 * K * VEC;
     for (int cb = 0; cb < C; cb += CB) {
         Acc<K, VEC> acc;
-        float *orow = out + (long long)id * C + cb;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            if constexpr (VEC == 4) {
-                const int ch = (k * 64 + lane) * 4;
-                float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
-            } else {
-                const int ch = k * 64 + lane;
-                acc.a[k] = (cb + ch < C) ? orow[ch] : 0.f;
-            }
-        }
-        Acc<K, VEC> acc0 = acc;
+        float *orow = g.out + (long long)id * C + cb;
+        acc_load<K, VEC>(acc, orow, cb, C, lane);
+        const Acc<K, VEC> acc0 = acc;
         int found = 0;
         for (int b = 0; b < p.B && found < expected; b++) {
-            const int cell = cell_of_id[(long long)b * p.n_rows + id];
-            if (cell < 0) continue;
-            const int czi = cell / (p.dimy * p.dimx);
-            const int rem = cell - czi * (p.dimy * p.dimx);
-            const int cyi = rem / p.dimx, cxi = rem - cyi * p.dimx;
-            const float cxw = p.ox + (float)cxi * p.vs, cyw = p.oy + (float)cyi * p.vs, czw = p.oz + (float)czi * p.vs;
-            const float fx = intr[b * 4 + 0], fy = intr[b * 4 + 1], mx = intr[b * 4 + 2], my = intr[b * 4 + 3];
+            float cxw, cyw, czw;
+            if (!voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
+            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
             for (int vbase = 0; vbase < p.V && found < expected; vbase += 64) {
                 const int v = vbase + lane;
                 int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
                 bool ne = false;
-                if (v < p.V) ne = voxel_box(viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, W, H, x0, y0, x1, y1);
+                if (v < p.V) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
                 unsigned long long vm = __ballot(ne);
                 while (vm && found < expected) {
                     const int l = __builtin_ctzll(vm);
@@ -565,31 +714,135 @@ __global__ __launch_bounds__(256) void k_gather(const float *__restrict__ feats,
                     const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
                     const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
                     const long long bv = (long long)b * p.V + vbase + l;
-                    scan_box<K, VEC, U>(feats + bv * HW * C, hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
+                    scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
                 }
             }
         }
         if (found != expected) {
             // the search boxes missed pixels (an ID labelling several cells, a degenerate pose...):
             // redo this voxel over whole images.  Correctness never depends on the boxes.
-            if (lane == 0 && cb == 0) atomicAdd(&status[ST_BOXMISS], 1);
+            if (lane == 0 && cb == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
             acc = acc0;
             found = 0;
             for (long long bv = 0; bv < (long long)p.B * p.V; bv++)
-                scan_box<K, VEC, U>(feats + bv * HW * C, hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
+                scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
         }
+        acc_store<K, VEC>(acc, orow, cb, C, lane);
+        if (cb == 0 && lane == 0) g.count[id] += found;   // K.cu:77 (one add of the per-call total)
+    }
+}
+
+// Heavy role: the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
+// in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
+// each wavefront sums its range in raster order, and the partial rows are combined through LDS in
+// wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
+// the serial order in the last bits only, well inside the 1e-4 bar).
+template <int K, int VEC, int U>
+__device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id, int expected,
+                                   float (*part)[64 * K * VEC], int *part_found, bool whole_image)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+    const int W = p.width, H = p.height, C = p.C;
+    const long long HW = (long long)H * W;
+    const float hh = box_half_edge(p);
+    const float zn = near_plane(p);
+    constexpr int CB = 64 * K * VEC;
+    constexpr int R = (CB + GW * 64 - 1) / (GW * 64);   // running-sum channels per thread
+    int found_total = 0;
+    for (int cb = 0; cb < C; cb += CB) {
+        float run[R];
+        float *orow = g.out + (long long)id * C + cb;
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            if constexpr (VEC == 4) {
-                const int ch = (k * 64 + lane) * 4;
-                if (cb + ch < C)
-                    *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
-            } else {
-                const int ch = k * 64 + lane;
-                if (cb + ch < C) orow[ch] = acc.a[k];
+        for (int r = 0; r < R; r++) {
+            const int c = tid + r * GW * 64;
+            run[r] = (c < CB && cb + c < C) ? orow[c] : 0.f;
+        }
+        found_total = 0;
+        for (int b = 0; b < p.B && found_total < expected; b++) {
+            float cxw = 0.f, cyw = 0.f, czw = 0.f;
+            if (!whole_image && !voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
+            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
+            for (int vbase = 0; vbase < p.V && found_total < expected; vbase += 64) {
+                const int v = vbase + lane;
+                int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
+                bool ne = v < p.V;
+                if (ne && !whole_image) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
+                unsigned long long vm = __ballot(ne);   // identical in every wavefront of the workgroup
+                while (vm && found_total < expected) {
+                    const int l = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
+                    const long long bv = (long long)b * p.V + vbase + l;
+                    const int per = (by1 - by0 + GW) / GW;
+                    const int ry0 = by0 + w * per, ry1 = min(by1, ry0 + per - 1);
+                    Acc<K, VEC> acc;
+#pragma unroll
+                    for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
+                    int f = 0;
+                    if (ry0 <= ry1)
+                        scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, bx0, ry0, bx1, ry1, cb, lane, acc, f);
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        if constexpr (VEC == 4)
+                            *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 4]) =
+                                make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+                        else
+                            part[w][k * 64 + lane] = acc.a[k];
+                    }
+                    if (lane == 0) part_found[w] = f;
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int c = tid + r * GW * 64;
+                        if (c < CB) {
+#pragma unroll
+                            for (int ww = 0; ww < GW; ww++) run[r] += part[ww][c];
+                        }
+                    }
+#pragma unroll
+                    for (int ww = 0; ww < GW; ww++) found_total += part_found[ww];
+                    __syncthreads();
+                }
             }
         }
-        if (cb == 0 && lane == 0) count[id] += found;   // K.cu:77 (one add of the per-call total)
+        if (found_total != expected) return false;   // caller retries over whole images; nothing stored yet
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int c = tid + r * GW * 64;
+            if (c < CB && cb + c < C) orow[c] = run[r];
+        }
+    }
+    if (tid == 0) g.count[id] += found_total;
+    return true;
+}
+
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long idl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
+    if (idl >= p.n_rows) return;
+    const int id = (int)idl;
+    const int expected = g.cnt_call[id];
+    if (expected == 0 || expected > g.heavy_t) return;
+    gather_voxel_wave<K, VEC, U>(g, p, id, expected, lane);
+}
+
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p)
+{
+    __shared__ __attribute__((aligned(16))) float part[GW][64 * K * VEC];
+    __shared__ int part_found[GW];
+    const int n_heavy = *g.n_heavy;
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const int id = g.heavy_list[h];
+        const int expected = g.cnt_call[id];
+        // first try the search boxes; on a pixel-count mismatch nothing was stored: redo over whole images
+        if (!gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, false)) {
+            if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+            gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
+        }
     }
 }
 
@@ -624,6 +877,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     if ((long long)B * V > 65535) return fail(VP_EINVAL, "B*V = %lld exceeds 65535", (long long)B * V);
     if ((long long)dimz * dimy * dimx >= (1ll << 31)) return fail(VP_EINVAL, "occupancy grid has >= 2^31 cells per batch");
     if ((long long)H * W >= (1ll << 31) || n_rows >= (1ll << 31)) return fail(VP_EINVAL, "image or row count >= 2^31");
+    if ((flags & VP_FLAG_SYNC) && (flags & VP_FLAG_PIPELINE)) return fail(VP_EINVAL, "VP_FLAG_SYNC and VP_FLAG_PIPELINE exclude each other");
     Params p;
     p.width = (int)(opts_host[0] + 0.5f);    // K.cu:403
     p.height = (int)(opts_host[1] + 0.5f);   // K.cu:404
@@ -640,74 +894,155 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     if (workspace_bytes < l.total) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, l.total);
     if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
     char *ws = (char *)workspace;
-    int *status = (int *)(ws + l.status);
+    hipStream_t s0 = (hipStream_t)stream_;
+
+    // buffer set and streams: plain calls use set 0 on the caller's stream only; pipelined calls alternate sets
+    // and run phase 1 + the heavy-voxel kernel on the side stream
+    const bool pipe = (flags & VP_FLAG_PIPELINE) != 0;
+    PipeState *ps = pipe_state(workspace, pipe);
+    if (pipe && !ps) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
+    int q = 0;
+    hipStream_t s1 = s0;
+    if (pipe) {
+        q = (int)(ps->calls & 1);
+        s1 = ps->side;
+    } else if (ps && (ps->used[0] || ps->used[1])) {
+        // a plain call after pipelined ones on this workspace: drain the side stream first
+        VP_HIP(hipStreamSynchronize(ps->side));
+        ps->used[0] = ps->used[1] = false;
+    }
+    int *status = (int *)(ws + l.status[q]);
     int *cell_of_id = (int *)(ws + l.cell_of_id);
     unsigned long long *mask64 = (unsigned long long *)(ws + l.mask64);
     unsigned char *dist = (unsigned char *)(ws + l.dist);
     unsigned char *dist_tmp = (unsigned char *)(ws + l.dist_tmp);
-    int *cnt_call = (int *)(ws + l.cnt_call);
-    ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab);
-    int *hit = (int *)(ws + l.hit);
-    hipStream_t stream = (hipStream_t)stream_;
+    int *cnt_call = (int *)(ws + l.cnt_call[q]);
+    int *heavy_list = (int *)(ws + l.heavy[q]);
+    ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab[q]);
+    int *hit = (int *)(ws + l.hit[q]);
 
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool prof = false;
-    {
-        std::lock_guard<std::mutex> g(g_prof.mu);
-        if (g_prof.on) {
-            prof = true;
-            for (int i = 0; i < 4; i++) prof = prof && ((ev[i] = g_prof.next()) != nullptr);
-        }
-    }
-    if (prof) VP_HIP(hipEventRecord(ev[0], stream));
-    VP_HIP(hipMemsetAsync(status, 0, ST_WORDS * sizeof(int), stream));
-    VP_HIP(hipMemsetAsync(cnt_call, 0, size_t(n_rows) * sizeof(int), stream));
     if (!(flags & VP_FLAG_REUSE_ACCEL)) {
-        VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), stream));
-        VP_HIP(hipMemsetAsync(mask64, 0, size_t(B) * l.nblk * sizeof(unsigned long long), stream));
+        // the tables are shared by both buffer sets: nothing of an earlier call may still be running
+        if (pipe) {
+            VP_HIP(hipStreamSynchronize(ps->side));
+            VP_HIP(hipStreamSynchronize(s0));
+        }
+        ProfSpan sp; sp.begin(0, s0);
+        VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), s0));
+        VP_HIP(hipMemsetAsync(mask64, 0, size_t(B) * l.nblk * sizeof(unsigned long long), s0));
         const long long cells = (long long)dimz * dimy * dimx;
         const int blocks = (int)((cells * B + 255) / 256 > 16384 ? 16384 : (cells * B + 255) / 256);
-        hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, stream, (const long long *)occ, cell_of_id,
+        hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, s0, (const long long *)occ, cell_of_id,
                            mask64, dimz, dimy, dimx, l.nby, l.nbx, l.nblk, B, (long long)n_rows);
         const int db = (int)((l.nblk * B + 255) / 256);
-        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, stream, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, B, 0);
-        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, stream, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, B, 1);
-        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, stream, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, B, 2);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, B, 0);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, B, 1);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, B, 2);
+        sp.end();
+        if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
     }
-    hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, stream, vmi, viewtab, B * V);
-    if (prof) VP_HIP(hipEventRecord(ev[1], stream));
-    if (flags & VP_FLAG_EXACT_MARCH)
-        hipLaunchKernelGGL(k_first_hit<false>, dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, stream,
-                           (const long long *)occ, vmi, intr, p, mask64, dist, l.nby, l.nbx, l.nblk, hit, cnt_call, status);
-    else
-        hipLaunchKernelGGL(k_first_hit<true>, dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, stream,
-                           (const long long *)occ, vmi, intr, p, mask64, dist, l.nby, l.nbx, l.nblk, hit, cnt_call, status);
-    if (prof) VP_HIP(hipEventRecord(ev[2], stream));
-    const int blocks2 = (int)((n_rows - 1 + 3) / 4);
-    if (blocks2 > 0) {
-        const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
-#define LAUNCH_GATHER(K, VEC, U)                                                                          \
-    hipLaunchKernelGGL((k_gather<K, VEC, U>), dim3(blocks2), dim3(256), 0, stream, feats, hit, viewtab,    \
-                       intr, cell_of_id, cnt_call, p, count, out, status)
-        if (vec_ok && C > 256) LAUNCH_GATHER(2, 4, 4);
-        else if (vec_ok) LAUNCH_GATHER(1, 4, 4);
-        else LAUNCH_GATHER(4, 1, 4);
+
+    if (pipe) {
+        VP_HIP(hipEventRecord(ps->entry, s0));
+        // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
+        if (ps->used[q]) VP_HIP(hipStreamWaitEvent(s1, ps->call_done[q], 0));
+    }
+
+    // ---- phase 1 (on s1) ----
+    int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
+    if (const char *e = getenv("VOXPROJ_HEAVY_T")) heavy_t = atoi(e) > 0 ? atoi(e) : heavy_t;
+    {
+        ProfSpan sp; sp.begin(0, s1);
+        VP_HIP(hipMemsetAsync(status, 0, ST_WORDS * sizeof(int), s1));
+        VP_HIP(hipMemsetAsync(cnt_call, 0, size_t(n_rows) * sizeof(int), s1));
+        hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
+        sp.end();
+    }
+    {
+        ProfSpan sp; sp.begin(1, s1);
+        const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
+        if (flags & VP_FLAG_EXACT_MARCH)
+            hipLaunchKernelGGL(k_first_hit<false>, grid, dim3(256), 0, s1, (const long long *)occ, vmi, intr, p, mask64,
+                               dist, l.nby, l.nbx, l.nblk, hit, cnt_call, heavy_list, heavy_t, status);
+        else
+            hipLaunchKernelGGL(k_first_hit<true>, grid, dim3(256), 0, s1, (const long long *)occ, vmi, intr, p, mask64,
+                               dist, l.nby, l.nbx, l.nblk, hit, cnt_call, heavy_list, heavy_t, status);
+        sp.end();
+    }
+    if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
+
+    // ---- phase 2 ----
+    GatherArgs g;
+    g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
+    g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
+    g.heavy_t = heavy_t; g.count = count; g.out = out; g.status = status;
+    const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int blocks_n = (int)((n_rows - 1 + 3) / 4);
+    const int blocks_h = 128;
+#define LAUNCH_GATHER(KERNEL, BLOCKS, THREADS, STREAM)                                              \
+    do {                                                                                            \
+        if (vec_ok && C > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), dim3(BLOCKS), dim3(THREADS), 0, STREAM, g, p); \
+        else if (vec_ok) hipLaunchKernelGGL((KERNEL<1, 4, 4>), dim3(BLOCKS), dim3(THREADS), 0, STREAM, g, p);       \
+        else hipLaunchKernelGGL((KERNEL<4, 1, 4>), dim3(BLOCKS), dim3(THREADS), 0, STREAM, g, p);                   \
+    } while (0)
+    if (pipe) {
+        // heavy voxels on the side stream, next to the normal gather.  They write output rows, so they must
+        // follow everything the caller queued before this call and the previous call's gather.
+        VP_HIP(hipStreamWaitEvent(s1, ps->entry, 0));
+        {
+            ProfSpan sp; sp.begin(3, s1);
+            LAUNCH_GATHER(k_gather_heavy, blocks_h, GW * 64, s1);
+            sp.end();
+        }
+        VP_HIP(hipEventRecord(ps->heavy_done[q], s1));
+        VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
+        if (blocks_n > 0) {
+            ProfSpan sp; sp.begin(2, s0);
+            LAUNCH_GATHER(k_gather, blocks_n, 256, s0);
+            sp.end();
+        }
+        VP_HIP(hipStreamWaitEvent(s0, ps->heavy_done[q], 0));
+        VP_HIP(hipEventRecord(ps->call_done[q], s0));
+        ps->used[q] = true;
+        ps->last_q = q;
+        ps->calls++;
+    } else {
+        {
+            ProfSpan sp; sp.begin(3, s0);
+            LAUNCH_GATHER(k_gather_heavy, blocks_h, GW * 64, s0);
+            sp.end();
+        }
+        if (blocks_n > 0) {
+            ProfSpan sp; sp.begin(2, s0);
+            LAUNCH_GATHER(k_gather, blocks_n, 256, s0);
+            sp.end();
+        }
+        if (ps) ps->last_q = 0;
+    }
 #undef LAUNCH_GATHER
-    }
-    if (prof) VP_HIP(hipEventRecord(ev[3], stream));
     VP_HIP(hipGetLastError());
     if (flags & VP_FLAG_SYNC) return vp_workspace_status(workspace, stream_);
+    return VP_OK;
+}
+
+static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WORDS] */)
+{
+    if (PipeState *ps = pipe_state(workspace, false)) VP_HIP(hipStreamSynchronize(ps->side));
+    VP_HIP(hipMemcpyAsync(st, workspace, 2 * align256(ST_WORDS * sizeof(int)), hipMemcpyDeviceToHost, stream));
+    VP_HIP(hipStreamSynchronize(stream));
     return VP_OK;
 }
 
 int vp_workspace_status(void *workspace, void *stream_)
 {
     if (!workspace) return fail(VP_EINVAL, "null workspace");
-    hipStream_t stream = (hipStream_t)stream_;
-    int st[ST_WORDS];
-    VP_HIP(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream));
-    VP_HIP(hipStreamSynchronize(stream));
-    if (st[ST_BADID])
+    static_assert(ST_WORDS * sizeof(int) == 256, "status block is one 256-byte slot");
+    int st[2 * ST_WORDS];
+    int rc = read_status(workspace, (hipStream_t)stream_, st);
+    if (rc != VP_OK) return rc;
+    PipeState *ps = pipe_state(workspace, false);
+    const bool second = ps && ps->used[1];
+    if (st[ST_BADID] || (second && st[ST_WORDS + ST_BADID]))
         return fail(VP_EBADID, "a ray hit an occupancy ID outside [1, n_rows): outputs are too small for the grid's IDs");
     return VP_OK;
 }
@@ -715,9 +1050,12 @@ int vp_workspace_status(void *workspace, void *stream_)
 int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream_)
 {
     if (!workspace || !host_words || n <= 0 || n > ST_WORDS) return fail(VP_EINVAL, "bad argument");
-    hipStream_t stream = (hipStream_t)stream_;
-    VP_HIP(hipMemcpyAsync(host_words, workspace, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, stream));
-    VP_HIP(hipStreamSynchronize(stream));
+    int st[2 * ST_WORDS];
+    int rc = read_status(workspace, (hipStream_t)stream_, st);
+    if (rc != VP_OK) return rc;
+    PipeState *ps = pipe_state(workspace, false);
+    const int q = ps ? ps->last_q : 0;
+    memcpy(host_words, st + q * ST_WORDS, size_t(n) * sizeof(int));
     return VP_OK;
 }
 
@@ -729,21 +1067,18 @@ int vp_profile_enable(int on)
     return VP_OK;
 }
 
-int vp_profile_read(double *ms3, int64_t *calls)
+int vp_profile_read(double *ms4, int64_t *launches4)
 {
-    if (!ms3 || !calls) return fail(VP_EINVAL, "null pointer argument");
+    if (!ms4 || !launches4) return fail(VP_EINVAL, "null pointer argument");
     std::lock_guard<std::mutex> g(g_prof.mu);
-    ms3[0] = ms3[1] = ms3[2] = 0.0;
-    const size_t n = g_prof.used / 4;
-    for (size_t i = 0; i < n; i++) {
-        VP_HIP(hipEventSynchronize(g_prof.pool[i * 4 + 3]));
-        for (int k = 0; k < 3; k++) {
-            float ms = 0.f;
-            VP_HIP(hipEventElapsedTime(&ms, g_prof.pool[i * 4 + k], g_prof.pool[i * 4 + k + 1]));
-            ms3[k] += ms;
-        }
+    for (int k = 0; k < 4; k++) { ms4[k] = 0.0; launches4[k] = 0; }
+    for (size_t i = 0; i < g_prof.used; i++) {
+        VP_HIP(hipEventSynchronize(g_prof.pool[i * 2 + 1]));
+        float ms = 0.f;
+        VP_HIP(hipEventElapsedTime(&ms, g_prof.pool[i * 2], g_prof.pool[i * 2 + 1]));
+        ms4[g_prof.kind[i]] += ms;
+        launches4[g_prof.kind[i]] += 1;
     }
-    *calls = (int64_t)n;
     g_prof.used = 0;
     return VP_OK;
 }
@@ -754,8 +1089,32 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
     (void)C;
     if (!workspace || !dst) return fail(VP_EINVAL, "null pointer argument");
     const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx);
-    VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + l.hit, size_t(B) * V * H * W * sizeof(int),
+    PipeState *ps = pipe_state(const_cast<void *>(workspace), false);
+    if (ps) VP_HIP(hipStreamSynchronize(ps->side));
+    const int q = ps ? ps->last_q : 0;
+    VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + l.hit[q], size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    return VP_OK;
+}
+
+int vp_workspace_release(void *workspace)
+{
+    std::lock_guard<std::mutex> g(g_pipe_mu);
+    for (size_t i = 0; i < g_pipes.size(); i++)
+        if (g_pipes[i].first == workspace) {
+            PipeState *ps = g_pipes[i].second;
+            (void)hipStreamSynchronize(ps->side);
+            (void)hipStreamDestroy(ps->side);
+            for (int q = 0; q < 2; q++) {
+                (void)hipEventDestroy(ps->fh_done[q]);
+                (void)hipEventDestroy(ps->heavy_done[q]);
+                (void)hipEventDestroy(ps->call_done[q]);
+            }
+            (void)hipEventDestroy(ps->entry);
+            delete ps;
+            g_pipes.erase(g_pipes.begin() + i);
+            break;
+        }
     return VP_OK;
 }
 

@@ -16,6 +16,7 @@ VP_OK = 0
 VP_FLAG_SYNC = 1
 VP_FLAG_REUSE_ACCEL = 2
 VP_FLAG_EXACT_MARCH = 4
+VP_FLAG_PIPELINE = 8
 
 _lib = None
 _lock = threading.Lock()
@@ -23,7 +24,7 @@ _lock = threading.Lock()
 EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
-    "vp_profile_enable", "vp_profile_read",
+    "vp_profile_enable", "vp_profile_read", "vp_workspace_release",
 ]
 
 
@@ -70,6 +71,8 @@ def lib():
             L.vp_profile_enable.argtypes = [ctypes.c_int]
             L.vp_profile_read.restype = ctypes.c_int
             L.vp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+            L.vp_workspace_release.restype = ctypes.c_int
+            L.vp_workspace_release.argtypes = [vp]
             _lib = L
     return _lib
 
@@ -96,11 +99,25 @@ class Workspace:
 
     def ensure(self, nbytes, device):
         import torch
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+        if self.buf is None or self.buf.numel() < nbytes + 256 or self.buf.device != device:
+            self.release()
             self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
             self.accel_key = None
-        ptr = self.buf.data_ptr()
-        return (ptr + 255) & ~255
+        return self.ptr()
+
+    def ptr(self):
+        return (self.buf.data_ptr() + 255) & ~255
+
+    def release(self):
+        """Drop the library's side stream/events for this buffer (before the memory is recycled)."""
+        if self.buf is not None and _lib is not None:
+            _lib.vp_workspace_release(self.ptr())
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 _workspaces = {}
@@ -115,7 +132,7 @@ def get_workspace(device):
 
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
-                         workspace=None, sync=True, reuse_accel=None, exact_march=None):
+                         workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False):
     """Call vp_project_features on torch CUDA tensors (already validated by the caller).
 
     opts5 / grid_origin3 are python sequences of floats.  Returns the Workspace used.
@@ -123,7 +140,9 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     alive) tensor object as in the previous call on this workspace, with an unchanged torch version
     counter -- a data_ptr match alone is not enough, the caching allocator hands freed addresses out
     again; True/False = force.  ``exact_march``: evaluate every ray sample (A/B arm of the leaping march;
-    default from env VOXPROJ_EXACT_MARCH).
+    default from env VOXPROJ_EXACT_MARCH).  ``pipeline``: asynchronous job mode (VP_FLAG_PIPELINE): phase 1 of
+    this call overlaps the previous call's gather; the caller must keep occ/vmi/intr alive and unchanged
+    until ``workspace_status`` (or a device synchronise) and must not pass sync.
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -139,8 +158,8 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
                        and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1")
     if exact_march is None:
         exact_march = os.environ.get("VOXPROJ_EXACT_MARCH", "0") == "1"
-    flags = ((VP_FLAG_SYNC if sync else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
-             | (VP_FLAG_EXACT_MARCH if exact_march else 0))
+    flags = ((VP_FLAG_SYNC if (sync and not pipeline) else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
+             | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream
@@ -162,7 +181,7 @@ def hit_image(ws, device):
     import torch
     B, V, H, W, C, dimz, dimy, dimx, n_rows = ws.last_shape
     dst = torch.empty((B, V, H, W), dtype=torch.int32, device=device)
-    ptr = (ws.buf.data_ptr() + 255) & ~255
+    ptr = ws.ptr()
     stream = torch.cuda.current_stream(device).cuda_stream
     check(lib().vp_copy_hit_image(ptr, dst.data_ptr(), B, V, H, W, C, dimz, dimy, dimx, n_rows, stream))
     torch.cuda.current_stream(device).synchronize()
@@ -170,13 +189,13 @@ def hit_image(ws, device):
 
 
 def counters(ws, device):
-    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss)."""
+    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss, n_heavy)."""
     import torch
     arr = (ctypes.c_int32 * 8)()
-    ptr = (ws.buf.data_ptr() + 255) & ~255
+    ptr = ws.ptr()
     stream = torch.cuda.current_stream(device).cuda_stream
     check(lib().vp_workspace_counters(ptr, arr, 8, stream))
-    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]))
+    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]), n_heavy=int(arr[2]))
 
 
 def profile_enable(on=True):
@@ -184,8 +203,17 @@ def profile_enable(on=True):
 
 
 def profile_read():
-    """dict(prep_ms, first_hit_ms, gather_ms, calls): summed HIP-event times since the last read."""
-    ms = (ctypes.c_double * 3)()
-    calls = ctypes.c_int64(0)
-    check(lib().vp_profile_read(ms, ctypes.byref(calls)))
-    return dict(prep_ms=ms[0], first_hit_ms=ms[1], gather_ms=ms[2], calls=int(calls.value))
+    """Summed HIP-event milliseconds and launch counts per kernel group since the last read."""
+    ms = (ctypes.c_double * 4)()
+    n = (ctypes.c_int64 * 4)()
+    check(lib().vp_profile_read(ms, n))
+    return dict(prep_ms=ms[0], first_hit_ms=ms[1], gather_ms=ms[2], heavy_ms=ms[3],
+                prep_launches=int(n[0]), first_hit_launches=int(n[1]), gather_launches=int(n[2]),
+                heavy_launches=int(n[3]))
+
+
+def workspace_status(ws, device):
+    """Synchronise and raise if any call on ``ws`` reported a device-side error (asynchronous callers)."""
+    import torch
+    stream = torch.cuda.current_stream(device).cuda_stream
+    check(lib().vp_workspace_status(ws.ptr(), stream))

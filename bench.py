@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="plain calls: phase 1 and 2 serial on one stream")
     ap.add_argument("--cpu-views", type=int, default=2, help="views in the cpu_baseline sample")
     return ap.parse_args()
 
@@ -120,11 +121,13 @@ def main():
         calls.append((slot, vs))
     vmis = [c2w[vs].reshape(-1).contiguous() for _, vs in calls]
 
+    pipeline = not a.no_pipeline
+
     def one_call(ci, sync=False):
         slot, vs = calls[ci]
         voxproj_host.project_features_raw(feats[:, slot:slot + len(vs)], occ, vmis[ci], intr, opts, count, out,
                                           origin, scene.voxel_size, workspace=ws, sync=sync,
-                                          reuse_accel=(ci > 0 or None))
+                                          reuse_accel=(ci > 0 or None), pipeline=(pipeline and not sync))
 
     def step():
         count.zero_()
@@ -136,7 +139,7 @@ def main():
             dist.all_reduce(count)
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
-    hit_px, touched, gather_bytes = 0, 0, 0
+    hit_px, touched, gather_bytes, cnt, max_px = 0, 0, 0, {}, 0
     for ci in range(len(calls)):
         count.zero_()
         one_call(ci, sync=True)
@@ -144,7 +147,10 @@ def main():
         hit_px += ph
         touched += nt
         gather_bytes += ph * C * 4 + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
-    cnt = voxproj_host.counters(ws, dev)
+        c1 = voxproj_host.counters(ws, dev)
+        for k in c1:
+            cnt[k] = cnt.get(k, 0) + c1[k]
+        max_px = max(max_px, int(count.max().item()))
 
     def barrier():
         if dist is not None:
@@ -160,6 +166,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    voxproj_host.workspace_status(ws, dev)
     prof = voxproj_host.profile_read()
     voxproj_host.profile_enable(False)
     if dist is not None:
@@ -170,7 +177,7 @@ def main():
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = n_vox * n_views / (dt / a.steps) / 1e6
-        launches = max(prof["calls"], 1)
+        launches = max(prof["gather_launches"], 1)
         gather_ms = prof["gather_ms"] / launches
         ach = (gather_bytes / len(calls)) / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
         # whole-path algorithmic bytes per step: feature rows + output RMW + counts + ID image w+r
@@ -187,8 +194,10 @@ def main():
             "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
             "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
                                   "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
-                                  "gather": round(prof["gather_ms"] / a.steps, 3)},
-            "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"],
+                                  "gather": round(prof["gather_ms"] / a.steps, 3),
+                                  "gather_heavy": round(prof["heavy_ms"] / a.steps, 3),
+                                  "overlapped": pipeline},
+            "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},

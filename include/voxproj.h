@@ -42,8 +42,15 @@ enum {
     VP_FLAG_REUSE_ACCEL = 2, /* the occupancy-derived tables in the workspace are still valid for
                                 this occupancy grid (same pointer, contents and n_rows): skip
                                 rebuilding them                                                    */
-    VP_FLAG_EXACT_MARCH = 4  /* A/B arm: evaluate every ray sample like K.cu:47-82 does instead of
+    VP_FLAG_EXACT_MARCH = 4, /* A/B arm: evaluate every ray sample like K.cu:47-82 does instead of
                                 leaping over provably empty space (same results, slower)           */
+    VP_FLAG_PIPELINE = 8     /* asynchronous job mode (excludes VP_FLAG_SYNC): phase 1 (ray-march) and the
+                                heavy-voxel kernel run on a library-owned side stream, so that phase 1 of
+                                this call overlaps the gather of the previous call on the same workspace.
+                                The caller promises that occ, vmi and intr are not being written by work
+                                still pending on `stream`, and keeps them alive and unchanged until the
+                                stream has been synchronised (vp_workspace_status does).  feats, count and
+                                out keep normal stream ordering.                                    */
 };
 
 int vp_abi_version(void);
@@ -98,7 +105,8 @@ int vp_workspace_status(void *workspace, void *stream);
  * Diagnostic counters of the last call on this workspace, copied to host_words[0..n) after a
  * stream synchronise: [0] = rays that hit an out-of-range ID, [1] = voxels whose search box
  * missed pixels and were rescanned over whole images (performance hint only; results are exact
- * either way).  No reference counterpart.
+ * either way), [2] = voxels summed by a whole workgroup because they collected more pixels than the
+ * heavy threshold in this call.  No reference counterpart.
  */
 int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream);
 
@@ -106,12 +114,19 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
  * Per-kernel device timing with HIP events recorded on the stream the kernels are launched on
  * (measurement harness; no reference counterpart -- the reference has no timers).
  * vp_profile_enable(1) starts recording for subsequent vp_project_features calls of this process;
- * vp_profile_read synchronises the recorded events, returns the summed milliseconds of
- * ms[0] = table preparation (memsets, ID->cell table, view table), ms[1] = k_first_hit (phase 1),
- * ms[2] = k_gather (phase 2) and the number of calls, then clears the record.
+ * vp_profile_read synchronises the recorded events and returns, per kernel group, the summed
+ * milliseconds and the number of launches: [0] = table preparation (memsets, occupancy tables, view
+ * table), [1] = k_first_hit (phase 1), [2] = k_gather (phase 2), [3] = k_gather_heavy; then clears
+ * the record.
  */
 int vp_profile_enable(int on);
-int vp_profile_read(double *ms3, int64_t *calls);
+int vp_profile_read(double *ms4, int64_t *launches4);
+
+/*
+ * Forgets the side stream / events the library keeps for a workspace that was used with
+ * VP_FLAG_PIPELINE (call before freeing or recycling the workspace memory).
+ */
+int vp_workspace_release(void *workspace);
 
 /*
  * Copies the first-hit ID image i32 [B,V,H,W] of the LAST vp_project_features call on this

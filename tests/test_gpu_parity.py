@@ -13,6 +13,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _no_heavy_path_by_default(monkeypatch):
+    # the bit-identical-sums assertions hold for voxels summed by ONE wavefront; keep the workgroup path
+    # (different, fixed summation tree) out of those tests.  test_heavy_voxels_* lowers it again.
+    monkeypatch.setenv("VOXPROJ_HEAVY_T", "100000000")
+
+
 def _gpu_call(feats, occ, c2w, intr, opts, origin, vs, count_t, out_t):
     import project_features_cuda as m
     B = feats.shape[0]
@@ -152,6 +159,29 @@ def test_id_labelling_several_cells_falls_back_to_full_scan(oracle_mod):
              expect_boxmiss=True)
 
 
+def test_heavy_voxels_use_the_workgroup_path(oracle_mod, monkeypatch):
+    # voxels that collect more than VOXPROJ_HEAVY_T pixels in a call are summed by a whole workgroup with a
+    # fixed summation tree: IDs/counts stay exact, sums within 1e-4 (not bit-identical to the serial order),
+    # and two runs agree bit for bit.
+    import voxproj_host
+    monkeypatch.setenv("VOXPROJ_HEAVY_T", "6")
+    s = make_scene(2000, 5, 48, 32, seed=31, room=(5.0, 4.0, 2.4))
+    for C in (16, 512, 7):
+        feats = make_features_np(5, 32, 48, C, seed=31)[None]
+        r, got, _ = _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size,
+                             s.n_vox + 1, bitwise=False)
+        ws = voxproj_host.get_workspace(torch.device(DEV))
+        assert voxproj_host.counters(ws, torch.device(DEV))["n_heavy"] > 50
+        _, got2, _ = _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size,
+                              s.n_vox + 1, bitwise=False)
+        assert got.tobytes() == got2.tobytes()
+    # an ID labelling several cells AND heavy: whole-image fallback of the workgroup path
+    occ = np.where(s.occ > 0, (s.occ % 5) + 1, 0).astype(np.int32)
+    feats = make_features_np(5, 32, 48, 8, seed=32)[None]
+    _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, 7,
+             expect_boxmiss=True, bitwise=False)
+
+
 def test_out_of_range_id_raises(oracle_mod):
     s = make_scene(2000, 1, 40, 24, seed=23, room=(5.0, 4.0, 2.4))
     feats = make_features_np(1, 24, 40, 8, seed=23)[None]
@@ -210,7 +240,8 @@ def test_full_resolution_view_properties(oracle_mod):
     ref = oracle_mod.first_hit(s.occ[None].astype(np.int64), s.c2w[:1].reshape(-1), s.intr[None], s.opts(),
                                s.grid_origin, s.voxel_size, 1, 1)
     assert np.array_equal(hits.cpu().numpy(), ref)
-    assert voxproj_host.counters(ws, torch.device(DEV)) == dict(bad_id=0, box_miss=0)
+    ctr = voxproj_host.counters(ws, torch.device(DEV))
+    assert ctr["bad_id"] == 0 and ctr["box_miss"] == 0
     flat = hits.reshape(-1).long()
     assert torch.equal(count_t.long(), torch.bincount(flat, minlength=n_rows) * (torch.arange(n_rows, device=DEV) > 0))
     # checksum of checksums: total over voxels == total over hit pixels (float64)
