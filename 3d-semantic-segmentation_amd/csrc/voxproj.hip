@@ -101,6 +101,9 @@ struct ProfSpan {
 // ------------------------------------------------------------------------------------------------
 // side stream + events for VP_FLAG_PIPELINE, one state per workspace pointer
 // ------------------------------------------------------------------------------------------------
+std::mutex g_pipe_mu;
+struct PipeState;
+std::vector<std::pair<void *, PipeState *>> g_pipes;
 struct PipeState {
     hipStream_t side = nullptr;
     hipEvent_t fh_done[2] = {nullptr, nullptr};      // phase 1 of buffer set q finished (side stream)
@@ -111,8 +114,22 @@ struct PipeState {
     long long calls = 0;
     int last_q = 0;
 };
-std::mutex g_pipe_mu;
-std::vector<std::pair<void *, PipeState *>> g_pipes;
+// offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
+std::vector<std::pair<const void *, size_t>> g_last_hit;
+void remember_hit(const void *workspace, size_t off)
+{
+    std::lock_guard<std::mutex> g(g_pipe_mu);
+    for (auto &kv : g_last_hit)
+        if (kv.first == workspace) { kv.second = off; return; }
+    g_last_hit.emplace_back(workspace, off);
+}
+bool recall_hit(const void *workspace, size_t &off)
+{
+    std::lock_guard<std::mutex> g(g_pipe_mu);
+    for (auto &kv : g_last_hit)
+        if (kv.first == workspace) { off = kv.second; return true; }
+    return false;
+}
 
 PipeState *pipe_state(void *workspace, bool create)
 {
@@ -168,7 +185,10 @@ struct Layout {
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int dimy, int dimx)
+// `capacity` = bytes of the caller's workspace (0 = compute the minimum).  The two per-call buffer sets sit
+// at offsets that depend only on (B, n_rows, grid dims, capacity), never on V/H/W, so that consecutive
+// pipelined calls of different V on one workspace cannot alias each other's buffers.
+Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int dimy, int dimx, size_t capacity = 0)
 {
     Layout l;
     size_t off = 0;
@@ -184,12 +204,15 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
     for (int q = 0; q < 2; q++) {
         l.cnt_call[q] = off; off += align256(size_t(n_rows) * sizeof(int));
         l.heavy[q] = off;    off += align256(size_t(n_rows) * sizeof(int));
-        l.viewtab[q] = off;  off += align256(size_t(B) * V * sizeof(ViewEntry));
     }
+    const size_t per_set = align256(size_t(B) * V * sizeof(ViewEntry)) + align256(size_t(B) * V * H * W * sizeof(int));
+    size_t half = per_set;
+    if (capacity > off + 2 * per_set) half = ((capacity - off) / 2) & ~size_t(255);
     for (int q = 0; q < 2; q++) {
-        l.hit[q] = off;      off += align256(size_t(B) * V * H * W * sizeof(int));
+        l.viewtab[q] = off + q * half;
+        l.hit[q] = l.viewtab[q] + align256(size_t(B) * V * sizeof(ViewEntry));
     }
-    l.total = off;
+    l.total = off + 2 * per_set;
     return l;
 }
 
@@ -890,7 +913,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     p.dimz = dimz; p.dimy = dimy; p.dimx = dimx;
     p.B = B; p.V = V; p.C = C; p.n_rows = n_rows;
 
-    const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx);
+    const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx, workspace_bytes);
     if (workspace_bytes < l.total) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, l.total);
     if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
     char *ws = (char *)workspace;
@@ -920,6 +943,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     int *heavy_list = (int *)(ws + l.heavy[q]);
     ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab[q]);
     int *hit = (int *)(ws + l.hit[q]);
+    remember_hit(workspace, l.hit[q]);
 
     if (!(flags & VP_FLAG_REUSE_ACCEL)) {
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
@@ -1086,13 +1110,13 @@ int vp_profile_read(double *ms4, int64_t *launches4)
 int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, int W, int C,
                       int dimz, int dimy, int dimx, int64_t n_rows, void *stream_)
 {
-    (void)C;
+    (void)C; (void)dimz; (void)dimy; (void)dimx; (void)n_rows;
     if (!workspace || !dst) return fail(VP_EINVAL, "null pointer argument");
-    const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx);
+    size_t off = 0;
+    if (!recall_hit(workspace, off)) return fail(VP_EINVAL, "no vp_project_features call has used this workspace");
     PipeState *ps = pipe_state(const_cast<void *>(workspace), false);
     if (ps) VP_HIP(hipStreamSynchronize(ps->side));
-    const int q = ps ? ps->last_q : 0;
-    VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + l.hit[q], size_t(B) * V * H * W * sizeof(int),
+    VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + off, size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
     return VP_OK;
 }
@@ -1115,6 +1139,8 @@ int vp_workspace_release(void *workspace)
             g_pipes.erase(g_pipes.begin() + i);
             break;
         }
+    for (size_t i = 0; i < g_last_hit.size(); i++)
+        if (g_last_hit[i].first == workspace) { g_last_hit.erase(g_last_hit.begin() + i); break; }
     return VP_OK;
 }
 

@@ -108,6 +108,9 @@ class Workspace:
     def ptr(self):
         return (self.buf.data_ptr() + 255) & ~255
 
+    def capacity(self):
+        return self.buf.numel() - (self.ptr() - self.buf.data_ptr())
+
     def release(self):
         """Drop the library's side stream/events for this buffer (before the memory is recycled)."""
         if self.buf is not None and _lib is not None:
@@ -167,7 +170,7 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
         rc = lib().vp_project_features(
             feats.data_ptr(), occ.data_ptr(), vmi.data_ptr(), intr.data_ptr(), o,
             count.data_ptr(), out.data_ptr(), g, ctypes.c_float(float(voxel_size)),
-            B, V, H, W, C, dimz, dimy, dimx, n_rows, ptr, need, stream, flags)
+            B, V, H, W, C, dimz, dimy, dimx, n_rows, ptr, ws.capacity(), stream, flags)
     if rc != VP_OK:
         ws.accel_key = None
         check(rc)

@@ -140,6 +140,7 @@ def main():
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px = 0, 0, 0, {}, 0
+    out.zero_()
     for ci in range(len(calls)):
         count.zero_()
         one_call(ci, sync=True)
@@ -151,6 +152,9 @@ def main():
         for k in c1:
             cnt[k] = cnt.get(k, 0) + c1[k]
         max_px = max(max_px, int(count.max().item()))
+
+    ref_checksum = out.double().sum(0)       # plain (unpipelined) result of one full pass on this rank
+    ref_abs = out.double().abs().sum(0)
 
     def barrier():
         if dist is not None:
@@ -168,6 +172,12 @@ def main():
     dt = time.perf_counter() - t0
     voxproj_host.workspace_status(ws, dev)
     prof = voxproj_host.profile_read()
+    if dist is None:
+        # the timed passes must have produced the same result as the plain pre-pass
+        assert int(count.sum().item()) == hit_px, "hit-count total changed between the pre-pass and the timed steps"
+        assert ((out.double().sum(0) - ref_checksum).abs() <= 1e-6 * ref_abs + 1e-9).all(), "feature sums changed"
+        last = voxproj_host.counters(ws, dev)
+        assert last["bad_id"] == 0 and last["box_miss"] == 0, last
     voxproj_host.profile_enable(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

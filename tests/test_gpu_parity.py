@@ -182,6 +182,47 @@ def test_heavy_voxels_use_the_workgroup_path(oracle_mod, monkeypatch):
              expect_boxmiss=True, bitwise=False)
 
 
+def test_pipelined_calls_of_varying_size(oracle_mod):
+    # VP_FLAG_PIPELINE: phase 1 of a call overlaps the previous call's gather on a side stream, two buffer
+    # sets alternate; calls of different V on one workspace must not disturb each other.
+    import voxproj_host
+    s = make_scene(2000, 11, 48, 32, seed=41, room=(5.0, 4.0, 2.4))
+    C = 16
+    feats = make_features_np(11, 32, 48, C, seed=41)
+    n_rows = s.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    dev = torch.device(DEV)
+    feats_t = torch.from_numpy(feats[None]).to(dev)
+    occ_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+    c2w_t = torch.from_numpy(s.c2w).to(dev)
+    intr_t = torch.from_numpy(s.intr[None]).to(dev)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    ws = voxproj_host.Workspace()
+    opts = [float(v) for v in s.opts()]
+    origin = [float(v) for v in s.grid_origin]
+    splits = [(0, 4), (4, 8), (8, 9), (9, 11), (0, 3), (3, 11)]
+    vmis = [c2w_t[a:b].reshape(-1).contiguous() for a, b in splits]
+    for rep in range(2):
+        for (a, b), vmi in zip(splits, vmis):
+            oracle_mod.project_features(feats[None, a:b], s.occ[None].astype(np.int64), s.c2w[a:b].reshape(-1),
+                                        s.intr[None], s.opts(), s.grid_origin, s.voxel_size, count, out)
+            voxproj_host.project_features_raw(feats_t[:, a:b], occ_t, vmi, intr_t, opts, count_t, out_t, origin,
+                                              s.voxel_size, workspace=ws, sync=False, pipeline=True)
+    voxproj_host.workspace_status(ws, dev)
+    assert voxproj_host.counters(ws, dev)["box_miss"] == 0
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    assert out_t.cpu().numpy().tobytes() == out.tobytes()
+    # a plain call on the same workspace after pipelined ones
+    voxproj_host.project_features_raw(feats_t[:, 0:2], occ_t, vmis[0][:32].contiguous(), intr_t, opts, count_t, out_t,
+                                      origin, s.voxel_size, workspace=ws, sync=True)
+    oracle_mod.project_features(feats[None, 0:2], s.occ[None].astype(np.int64), s.c2w[0:2].reshape(-1),
+                                s.intr[None], s.opts(), s.grid_origin, s.voxel_size, count, out)
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    assert out_t.cpu().numpy().tobytes() == out.tobytes()
+
+
 def test_out_of_range_id_raises(oracle_mod):
     s = make_scene(2000, 1, 40, 24, seed=23, room=(5.0, 4.0, 2.4))
     feats = make_features_np(1, 24, 40, 8, seed=23)[None]
