@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -105,7 +106,9 @@ std::mutex g_pipe_mu;
 struct PipeState;
 std::vector<std::pair<void *, PipeState *>> g_pipes;
 struct PipeState {
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;    // phase 1
+    hipStream_t side2 = nullptr;   // heavy-voxel kernel (its big workgroups are slow to place next to the gather;
+                                   // on a stream of its own it cannot hold up the next call's phase 1)
     hipEvent_t fh_done[2] = {nullptr, nullptr};      // phase 1 of buffer set q finished (side stream)
     hipEvent_t heavy_done[2] = {nullptr, nullptr};   // heavy-voxel kernel of set q finished (side stream)
     hipEvent_t call_done[2] = {nullptr, nullptr};    // everything of the call that used set q finished (caller's stream)
@@ -138,7 +141,8 @@ PipeState *pipe_state(void *workspace, bool create)
         if (kv.first == workspace) return kv.second;
     if (!create) return nullptr;
     PipeState *ps = new PipeState();
-    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ps->side2, hipStreamNonBlocking) == hipSuccess;
     for (int q = 0; q < 2 && ok; q++)
         ok = hipEventCreateWithFlags(&ps->fh_done[q], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ps->heavy_done[q], hipEventDisableTiming) == hipSuccess &&
@@ -176,7 +180,7 @@ struct ViewEntry {
 // position does not depend on the image shape -> VP_FLAG_REUSE_ACCEL)
 // ------------------------------------------------------------------------------------------------
 struct Layout {
-    size_t cell_of_id, mask64, dist, dist_tmp;           // occupancy-derived tables (shared)
+    size_t cell_of_id, mask64, near2, dist, dist_tmp;    // occupancy-derived tables (shared)
     size_t status[2], cnt_call[2], heavy[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
     size_t total;
     int nbx, nby, nbz;
@@ -193,12 +197,13 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
     Layout l;
     size_t off = 0;
     l.nbx = (dimx + 3) / 4; l.nby = (dimy + 3) / 4; l.nbz = (dimz + 3) / 4;
-    l.nblk = (long long)l.nbx * l.nby * l.nbz;
+    l.nblk = ((long long)l.nbx * l.nby * l.nbz + 15) & ~15ll;   // padded: per-batch tables stay 16-byte aligned
     // status words of set 0 come first: vp_workspace_status/counters read the head of the workspace
     l.status[0] = off;   off += align256(ST_WORDS * sizeof(int));
     l.status[1] = off;   off += align256(ST_WORDS * sizeof(int));
     l.cell_of_id = off;  off += align256(size_t(B) * size_t(n_rows) * sizeof(int));
     l.mask64 = off;      off += align256(size_t(B) * l.nblk * sizeof(unsigned long long));
+    l.near2 = off;       off += align256(size_t(B) * l.nblk * 16);
     l.dist = off;        off += align256(size_t(B) * l.nblk);
     l.dist_tmp = off;    off += align256(size_t(B) * l.nblk);
     for (int q = 0; q < 2; q++) {
@@ -231,6 +236,40 @@ __device__ __forceinline__ int f2i_sat(float v)
     if (v != v) return 0;
     v = fminf(fmaxf(v, -2147483648.0f), 2147483520.0f);
     return (int)v;
+}
+
+// J repetitions of t = fl(t + inc), computed without J dependent additions.
+// While t stays inside one binade [T, 2T), T = 2^e > inc, every addition rounds to the same grid of spacing
+// u = ulp(T): fl(t + inc) = t + g with g = inc rounded to a multiple of u (unless inc lies exactly half-way
+// between two multiples, where round-to-even depends on t; that binade is stepped one addition at a time).
+// g = fl(T + inc) - T.  Let m be the largest count with t + m*g <= 2T - u: for each of those m steps the exact
+// sum t_i + inc is below 2T, so the result is t_i + g, and t + m*g is exactly representable.  m is the floor
+// of an IEEE quotient of two multiples of u, which cannot round across an integer ("closed-form
+// leap").  The step that crosses the binade edge is one real addition.  All operations are IEEE binary32.
+__device__ __forceinline__ float advance_steps(float t, float inc, int J, float tEnd)
+{
+    while (J > 0 && t < tEnd) {
+        const unsigned eb = __float_as_uint(t) & 0x7f800000u;
+        const float T = __uint_as_float(eb);
+        const float T2 = __uint_as_float(eb + (1u << 23));
+        const float u = __uint_as_float(eb - (23u << 23));
+        const float g = (T + inc) - T;
+        const float r = inc - g;
+        bool fast = (eb >= (30u << 23)) && (eb < (0xfeu << 23)) && (inc < T) && (g > 0.0f) && (fabsf(r) * 2.0f != u);
+        int m = 0;
+        if (fast) {
+            const float A = (T2 - u) - t;
+            m = min(J, (int)floorf(A / g));
+        }
+        if (m > 0) {
+            t = t + (float)m * g;
+            J -= m;
+        } else {
+            t += inc;
+            J -= 1;
+        }
+    }
+    return t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -289,6 +328,49 @@ __global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__
     dst[i] = (unsigned char)best;
 }
 
+// Near field: for every cell of every block within one block of an occupied block, the Chebyshev distance in
+// CELLS to the nearest occupied cell, capped at 3 ("3 or more"), stored as two bit planes per 4x4x4 block
+// (nd = bit of .x | bit of .y << 1; nd == 0 <=> the cell is occupied).  One wavefront per block.
+__device__ __forceinline__ bool occ_bit(const unsigned long long *__restrict__ mask_b, int x, int y, int z,
+                                        int dimz, int dimy, int dimx, int nby, int nbx)
+{
+    if ((unsigned)x >= (unsigned)dimx || (unsigned)y >= (unsigned)dimy || (unsigned)z >= (unsigned)dimz) return false;
+    const unsigned long long m = mask_b[((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2)];
+    return (m >> (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))) & 1ull;
+}
+
+__global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__restrict__ mask64,
+                                                    const unsigned char *__restrict__ dist, ulonglong2 *near2,
+                                                    int dimz, int dimy, int dimx, int nbz, int nby, int nbx,
+                                                    long long nblk, int B)
+{
+    const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long long nreal = (long long)nbz * nby * nbx;
+    if (wid >= nreal * B) return;
+    const int b = (int)(wid / nreal);
+    const int blk = (int)(wid - (long long)b * nreal);
+    const unsigned long long *mask_b = mask64 + (long long)b * nblk;
+    int nd = 3;
+    if (dist[(long long)b * nblk + blk] <= 1) {
+        const int bz = blk / (nby * nbx), r = blk - bz * (nby * nbx), by = r / nbx, bx = r - by * nbx;
+        const int x = bx * 4 + (lane & 3), y = by * 4 + ((lane >> 2) & 3), z = bz * 4 + (lane >> 4);
+        if (occ_bit(mask_b, x, y, z, dimz, dimy, dimx, nby, nbx)) {
+            nd = 0;
+        } else {
+            for (int rad = 1; rad <= 2 && nd == 3; rad++)
+                for (int dz = -rad; dz <= rad && nd == 3; dz++)
+                    for (int dy = -rad; dy <= rad && nd == 3; dy++)
+                        for (int dx = -rad; dx <= rad; dx++) {
+                            if (max(abs(dx), max(abs(dy), abs(dz))) != rad) continue;
+                            if (occ_bit(mask_b, x + dx, y + dy, z + dz, dimz, dimy, dimx, nby, nbx)) { nd = rad; break; }
+                        }
+        }
+    }
+    const unsigned long long lo = __ballot(nd & 1), hi = __ballot(nd & 2);
+    if (lane == 0) near2[(long long)b * nblk + blk] = make_ulonglong2(lo, hi);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_viewtab: invert each view's 3x3 (double precision) for the phase-2 search boxes
 // ------------------------------------------------------------------------------------------------
@@ -333,21 +415,32 @@ __global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
 //     for samples that found an occupied cell (it gates nothing else).
 // Every evaluated sample uses the reference's exact fp32 operations, so the first-hit ID is identical.
 // ------------------------------------------------------------------------------------------------
-template <bool ACCEL>
-__global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__ occ,
+// MODE 0: reference loop; 1: leaping march, distance field read through L2; 2: leaping march with the
+// block distance field staged in LDS by the workgroup (32x32-pixel workgroups, two per CU).
+template <int MODE, int WX, int WY>
+__global__ __launch_bounds__(64 * WX * WY) void k_first_hit(const long long *__restrict__ occ,
                                                    const float *__restrict__ vmi,
                                                    const float *__restrict__ intr, Params p,
-                                                   const unsigned long long *__restrict__ mask64,
+                                                   const ulonglong2 *__restrict__ near2,
                                                    const unsigned char *__restrict__ dist,
                                                    int nby, int nbx, long long nblk,
                                                    int *__restrict__ hit, int *cnt_call, int *heavy_list,
                                                    int heavy_t, int *status)
 {
+    constexpr bool ACCEL = MODE != 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dist[];
     const int bv = blockIdx.z;
     const int b = bv / p.V;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int x = blockIdx.x * (8 * WX) + (wave % WX) * 8 + (lane & 7);
+    const int y = blockIdx.y * (8 * WY) + (wave / WX) * 8 + (lane >> 3);
+    if constexpr (MODE == 2) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(dist + (long long)b * nblk);   // 256-byte aligned per batch
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_dist);
+        const int n16 = (int)((nblk + 15) >> 4);
+        for (int i = threadIdx.x; i < n16; i += 64 * WX * WY) dst[i] = src[i];
+        __syncthreads();
+    }
     if (x >= p.width || y >= p.height) return;
 
     const float *m = vmi + (long long)bv * 16;           // K.cu:178-179 (row-major float4x4)
@@ -396,7 +489,7 @@ __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__
             t += p.inc;
         }
     } else {
-        const unsigned long long *mask_b = mask64 + (long long)b * nblk;
+        const ulonglong2 *near_b = near2 + (long long)b * nblk;
         const unsigned char *dist_b = dist + (long long)b * nblk;
         const float rvs = 1.0f / p.vs;
         // upper bound of the per-step motion in cells (1% covers the rounding of t += inc and of rvs)
@@ -404,47 +497,48 @@ __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__
         // leaping is allowed only where fp32 position error stays far below one cell and the step count
         // is sane; otherwise every sample is evaluated (still exact, just slower)
         const float span = (fabsf(cpx) + fabsf(cpy) + fabsf(cpz) + fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(tEnd)) * fabsf(rvs);
-        const bool leap_ok = (span < 131072.0f) && (fabsf(tEnd) < 1.0e5f * fabsf(p.inc)) && (dcell == dcell) && (dcell < 1.0e6f);
+        const bool leap_ok = (span < 131072.0f) & (fabsf(tEnd) < 1.0e5f * fabsf(p.inc)) & (dcell == dcell) & (dcell < 1.0e6f);
         const float inv_dcell = leap_ok ? 0.999f / dcell : 0.0f;
         int cur_blk = -1, cur_d = 0;
-        unsigned long long cur_mask = 0ull;
+        unsigned long long cur_lo = 0ull, cur_hi = 0ull;
+        int dbg_leap = 0, dbg_fine = 0;
         while (t < tEnd) {
             const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
             const float ax = px - p.ox, ay = py - p.oy, az = pz - p.oz;
             const float qx = ax * rvs, qy = ay * rvs, qz = az * rvs;
             const float rx = rintf(qx), ry = rintf(qy), rz = rintf(qz);
-            const bool safe = (fabsf(qx - rx) < __builtin_fmaf(fabsf(qx), -0x1p-21f, 0.5f)) &&
-                              (fabsf(qy - ry) < __builtin_fmaf(fabsf(qy), -0x1p-21f, 0.5f)) &&
+            const bool safe = (fabsf(qx - rx) < __builtin_fmaf(fabsf(qx), -0x1p-21f, 0.5f)) &
+                              (fabsf(qy - ry) < __builtin_fmaf(fabsf(qy), -0x1p-21f, 0.5f)) &
                               (fabsf(qz - rz) < __builtin_fmaf(fabsf(qz), -0x1p-21f, 0.5f));
-            int ix, iy, iz;
-            if (safe) {   // |q| < 2^20 here, conversions are exact
-                ix = (int)rx; iy = (int)ry; iz = (int)rz;
-            } else {
+            int ix = (int)rx, iy = (int)ry, iz = (int)rz;   // exact when safe (|q| < 2^20)
+            if (__builtin_expect(!safe, 0)) {
                 ix = f2i_sat(round_half_away(ax / p.vs));
                 iy = f2i_sat(round_half_away(ay / p.vs));
                 iz = f2i_sat(round_half_away(az / p.vs));
             }
             int D = 0;   // lower bound on the Chebyshev cell distance from (ix,iy,iz) to an occupied cell
-            if ((unsigned)ix < (unsigned)p.dimx && (unsigned)iy < (unsigned)p.dimy && (unsigned)iz < (unsigned)p.dimz) {
+            const bool ing = ((unsigned)ix < (unsigned)p.dimx) & ((unsigned)iy < (unsigned)p.dimy) & ((unsigned)iz < (unsigned)p.dimz);
+            if (__builtin_expect(ing, 1)) {
                 const int blk = ((iz >> 2) * nby + (iy >> 2)) * nbx + (ix >> 2);
                 if (blk != cur_blk) {
                     cur_blk = blk;
-                    cur_d = dist_b[blk];
-                    if (cur_d == 0) cur_mask = mask_b[blk];
-                }
-                if (cur_d == 0) {
-                    const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
-                    if ((cur_mask >> bit) & 1ull) {
-                        const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
-                        const float u = fx * (camx / camz) + mx;
-                        const float v = fy * (camy / camz) + my;
-                        if ((u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh)) {
-                            id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
-                            if (id != 0) break;
-                        }
+                    cur_d = (MODE == 2) ? lds_dist[blk] : dist_b[blk];
+                    if (cur_d <= 1) {
+                        const ulonglong2 n2 = near_b[blk];
+                        cur_lo = n2.x; cur_hi = n2.y;
                     }
-                } else {
-                    D = (cur_d - 1) * 4 + 1;
+                }
+                const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
+                const int nd = (int)((cur_lo >> bit) & 1ull) | ((int)((cur_hi >> bit) & 1ull) << 1);
+                D = cur_d <= 1 ? nd : (cur_d - 1) * 4 + 1;
+                if (__builtin_expect((cur_d <= 1) & (nd == 0), 0)) {
+                    const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
+                    const float u = fx * (camx / camz) + mx;
+                    const float v = fy * (camy / camz) + my;
+                    if ((u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh)) {
+                        id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
+                        if (id != 0) break;
+                    }
                 }
             } else if (leap_ok) {
                 const int lim = 1 << 29;
@@ -454,16 +548,26 @@ __global__ __launch_bounds__(256) void k_first_hit(const long long *__restrict__
                 const int ez = jz < 0 ? -jz : (jz >= p.dimz ? jz - p.dimz + 1 : 0);
                 const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
                 const int kx = min(max(jx, 0), p.dimx - 1), ky = min(max(jy, 0), p.dimy - 1), kz = min(max(jz, 0), p.dimz - 1);
-                const int dd = dist_b[((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2)];
+                const int cb_ = ((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2);
+                const int dd = (MODE == 2) ? lds_dist[cb_] : dist_b[cb_];
                 const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
                 D = max(dbox, din - dbox);
             }
+            if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
             t += p.inc;
-            if (D >= 2) {
-                int J = (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f);
-                for (; J >= 4 && t < tEnd; J -= 4) { t += p.inc; t += p.inc; t += p.inc; t += p.inc; }
-                for (; J > 0 && t < tEnd; J--) t += p.inc;
-            }
+            // skip the J = floor((D - 1.5) / dcell) samples that cannot reach an occupied cell
+            int J = D >= 2 ? (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f) : 0;
+            t = J > 0 ? t + p.inc : t;
+            t = J > 1 ? t + p.inc : t;
+            t = J > 2 ? t + p.inc : t;
+            t = J > 3 ? t + p.inc : t;
+            t = J > 4 ? t + p.inc : t;
+            t = J > 5 ? t + p.inc : t;
+            if (__builtin_expect(J > 6, 0)) t = advance_steps(t, p.inc, J - 6, tEnd);
+        }
+        if (heavy_t < 0) {   // diagnostic build path (VOXPROJ_DEBUG_EVALS): per-ray evaluation counts instead of IDs
+            hit[((long long)bv * p.height + y) * p.width + x] = (dbg_leap << 16) | dbg_fine;
+            return;
         }
     }
     if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
@@ -932,11 +1036,13 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     } else if (ps && (ps->used[0] || ps->used[1])) {
         // a plain call after pipelined ones on this workspace: drain the side stream first
         VP_HIP(hipStreamSynchronize(ps->side));
+        VP_HIP(hipStreamSynchronize(ps->side2));
         ps->used[0] = ps->used[1] = false;
     }
     int *status = (int *)(ws + l.status[q]);
     int *cell_of_id = (int *)(ws + l.cell_of_id);
     unsigned long long *mask64 = (unsigned long long *)(ws + l.mask64);
+    ulonglong2 *near2 = (ulonglong2 *)(ws + l.near2);
     unsigned char *dist = (unsigned char *)(ws + l.dist);
     unsigned char *dist_tmp = (unsigned char *)(ws + l.dist_tmp);
     int *cnt_call = (int *)(ws + l.cnt_call[q]);
@@ -949,6 +1055,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
         if (pipe) {
             VP_HIP(hipStreamSynchronize(ps->side));
+            VP_HIP(hipStreamSynchronize(ps->side2));
             VP_HIP(hipStreamSynchronize(s0));
         }
         ProfSpan sp; sp.begin(0, s0);
@@ -962,6 +1069,9 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
         hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, B, 0);
         hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, B, 1);
         hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, B, 2);
+        const long long near_waves = (long long)l.nbz * l.nby * l.nbx * B;
+        hipLaunchKernelGGL(k_build_near, dim3((unsigned)((near_waves + 3) / 4)), dim3(256), 0, s0, mask64, (const unsigned char *)dist,
+                           near2, dimz, dimy, dimx, l.nbz, l.nby, l.nbx, l.nblk, B);
         sp.end();
         if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
     }
@@ -975,6 +1085,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     // ---- phase 1 (on s1) ----
     int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
     if (const char *e = getenv("VOXPROJ_HEAVY_T")) heavy_t = atoi(e) > 0 ? atoi(e) : heavy_t;
+    if (getenv("VOXPROJ_DEBUG_EVALS")) heavy_t = -1;   // diagnostics only: the hit image then holds evaluation counts
     {
         ProfSpan sp; sp.begin(0, s1);
         VP_HIP(hipMemsetAsync(status, 0, ST_WORDS * sizeof(int), s1));
@@ -984,13 +1095,26 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     }
     {
         ProfSpan sp; sp.begin(1, s1);
-        const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
-        if (flags & VP_FLAG_EXACT_MARCH)
-            hipLaunchKernelGGL(k_first_hit<false>, grid, dim3(256), 0, s1, (const long long *)occ, vmi, intr, p, mask64,
-                               dist, l.nby, l.nbx, l.nblk, hit, cnt_call, heavy_list, heavy_t, status);
-        else
-            hipLaunchKernelGGL(k_first_hit<true>, grid, dim3(256), 0, s1, (const long long *)occ, vmi, intr, p, mask64,
-                               dist, l.nby, l.nbx, l.nblk, hit, cnt_call, heavy_list, heavy_t, status);
+#define FH_ARGS (const long long *)occ, vmi, intr, p, near2, dist, l.nby, l.nbx, l.nblk, hit, cnt_call, heavy_list, heavy_t, status
+        const size_t lds_bytes = (size_t(l.nblk) + 15) & ~size_t(15);
+        const bool lds_ok = lds_bytes <= 80 * 1024 && !getenv("VOXPROJ_NO_LDS_DIST");
+        if (flags & VP_FLAG_EXACT_MARCH) {
+            hipLaunchKernelGGL((k_first_hit<0, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, s1, FH_ARGS);
+        } else if (lds_ok) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                VP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_first_hit<2, 4, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            size_t lds_req = lds_bytes;
+            if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = std::max(lds_req, size_t(atoi(e)) * 1024);
+            if (lds_req > 160 * 1024) lds_req = 160 * 1024;
+            hipLaunchKernelGGL((k_first_hit<2, 4, 4>), dim3((W + 31) / 32, (H + 31) / 32, B * V), dim3(1024), lds_req, s1, FH_ARGS);
+        } else {
+            hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, s1, FH_ARGS);
+        }
+#undef FH_ARGS
         sp.end();
     }
     if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
@@ -1012,13 +1136,15 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     if (pipe) {
         // heavy voxels on the side stream, next to the normal gather.  They write output rows, so they must
         // follow everything the caller queued before this call and the previous call's gather.
-        VP_HIP(hipStreamWaitEvent(s1, ps->entry, 0));
+        hipStream_t s2 = ps->side2;
+        VP_HIP(hipStreamWaitEvent(s2, ps->entry, 0));
+        VP_HIP(hipStreamWaitEvent(s2, ps->fh_done[q], 0));
         {
-            ProfSpan sp; sp.begin(3, s1);
-            LAUNCH_GATHER(k_gather_heavy, blocks_h, GW * 64, s1);
+            ProfSpan sp; sp.begin(3, s2);
+            LAUNCH_GATHER(k_gather_heavy, blocks_h, GW * 64, s2);
             sp.end();
         }
-        VP_HIP(hipEventRecord(ps->heavy_done[q], s1));
+        VP_HIP(hipEventRecord(ps->heavy_done[q], s2));
         VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
         if (blocks_n > 0) {
             ProfSpan sp; sp.begin(2, s0);
@@ -1051,7 +1177,10 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
 
 static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WORDS] */)
 {
-    if (PipeState *ps = pipe_state(workspace, false)) VP_HIP(hipStreamSynchronize(ps->side));
+    if (PipeState *ps = pipe_state(workspace, false)) {
+        VP_HIP(hipStreamSynchronize(ps->side));
+        VP_HIP(hipStreamSynchronize(ps->side2));
+    }
     VP_HIP(hipMemcpyAsync(st, workspace, 2 * align256(ST_WORDS * sizeof(int)), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
     return VP_OK;
@@ -1115,7 +1244,10 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
     size_t off = 0;
     if (!recall_hit(workspace, off)) return fail(VP_EINVAL, "no vp_project_features call has used this workspace");
     PipeState *ps = pipe_state(const_cast<void *>(workspace), false);
-    if (ps) VP_HIP(hipStreamSynchronize(ps->side));
+    if (ps) {
+        VP_HIP(hipStreamSynchronize(ps->side));
+        VP_HIP(hipStreamSynchronize(ps->side2));
+    }
     VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + off, size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
     return VP_OK;
@@ -1128,7 +1260,9 @@ int vp_workspace_release(void *workspace)
         if (g_pipes[i].first == workspace) {
             PipeState *ps = g_pipes[i].second;
             (void)hipStreamSynchronize(ps->side);
+            (void)hipStreamSynchronize(ps->side2);
             (void)hipStreamDestroy(ps->side);
+            (void)hipStreamDestroy(ps->side2);
             for (int q = 0; q < 2; q++) {
                 (void)hipEventDestroy(ps->fh_done[q]);
                 (void)hipEventDestroy(ps->heavy_done[q]);
