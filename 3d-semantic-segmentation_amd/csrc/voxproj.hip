@@ -1112,7 +1112,9 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
             if (lds_req > 160 * 1024) lds_req = 160 * 1024;
             hipLaunchKernelGGL((k_first_hit<2, 4, 4>), dim3((W + 31) / 32, (H + 31) / 32, B * V), dim3(1024), lds_req, s1, FH_ARGS);
         } else {
-            hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, s1, FH_ARGS);
+            size_t lds_req = 0;   // a dynamic-LDS request caps this kernel's workgroups per CU (pipelined mode)
+            if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
+            hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), lds_req, s1, FH_ARGS);
         }
 #undef FH_ARGS
         sp.end();
@@ -1127,11 +1129,13 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
     const int blocks_h = 128;
+    size_t glds = 0;   // experiment knob: a dynamic-LDS request caps the gather's workgroups per CU
+    if (const char *e = getenv("VOXPROJ_GATHER_LDS_KB")) glds = size_t(atoi(e)) * 1024;
 #define LAUNCH_GATHER(KERNEL, BLOCKS, THREADS, STREAM)                                              \
     do {                                                                                            \
-        if (vec_ok && C > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), dim3(BLOCKS), dim3(THREADS), 0, STREAM, g, p); \
-        else if (vec_ok) hipLaunchKernelGGL((KERNEL<1, 4, 4>), dim3(BLOCKS), dim3(THREADS), 0, STREAM, g, p);       \
-        else hipLaunchKernelGGL((KERNEL<4, 1, 4>), dim3(BLOCKS), dim3(THREADS), 0, STREAM, g, p);                   \
+        if (vec_ok && C > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p); \
+        else if (vec_ok) hipLaunchKernelGGL((KERNEL<1, 4, 4>), dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p);       \
+        else hipLaunchKernelGGL((KERNEL<4, 1, 4>), dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p);                   \
     } while (0)
     if (pipe) {
         // heavy voxels on the side stream, next to the normal gather.  They write output rows, so they must
