@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="R2", choices=sorted(WORKLOADS))
-    ap.add_argument("--chunk", type=int, default=4, help="views per vp_project_features call")
+    ap.add_argument("--chunk", type=int, default=16, help="views per vp_project_features call")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
