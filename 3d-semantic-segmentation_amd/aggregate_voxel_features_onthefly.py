@@ -1,0 +1,259 @@
+"""Scene-level feature aggregation -- the named entry point, in one process.
+
+Counterpart of the reference's aggregate_voxel_features_onthefly.py
+(cuda_project_image_to_sparse_voxel/aggregate_voxel_features_onthefly.py:101-453).  The reference runs,
+PER VIEW, three Python sub-processes glued by ~1 GB ``.pt`` files (build_sparse_occupancy /
+prepare_tensor_data / debug_project_features) and then adds the per-view result into Python dicts keyed by
+(z,y,x).  Here the same steps run in-process on the GPU; the output files keep the reference's names, keys,
+dtypes and row order, so stage 5 (voxel_to_gaussian/voxeltoGaussian_logits.py:40-46) reads them unchanged:
+
+  ALL_nonzero_voxel_features_{n_views}_vox{N}.pt   xyz f32 [n,3], avg_feats f16 [n,C], voxel_coords i32 [n,3]   (AGG:443-451)
+  checkpoint_features_{k}.pt  (every 20 views)     xyz f64, avg_feats f16, hit_count i32, voxel_coords i32      (AGG:318-352)
+
+Two modes:
+
+  --mode parity  (default) one projector call per view; the per-view pixel sums are rounded to fp16
+                 (DPF:252), the running per-voxel sum is an fp16 tensor updated with fp16 adds (AGG:309-312),
+                 "hit_count" counts VIEWS (AGG:313) and avg = sum / hit_count in fp16 (AGG:385).
+                 Rows appear in dict-insertion order: by first view that hit the voxel, then by voxel ID.
+                 This reproduces the reference's file bit for bit (tests/test_aggregator_*.py check it against
+                 oracle.aggregate_views).
+  --mode fast    multi-view pipelined calls (VP_FLAG_PIPELINE), fp32 sums, pixel counts and view counts kept
+                 exactly; avg = fp32 sum / views (the same definition without the per-view fp16 round trips),
+                 rows in voxel-ID order; additionally saves sum/count/views in ``*_fp32.pt``.  With torchrun,
+                 rank r projects views r::G and one all-reduce (RCCL) combines {sum, count, views}.
+
+Constants below keep the reference's names (AGG:18-29,106,209,318); every one can be overridden on the
+command line, and ``--first_only`` keeps its meaning (AGG:14,112-113).
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+import torch
+
+import build_sparse_occupancy as bso
+import prepare_tensor_data as ptd
+import voxproj_host
+from debug_project_features import build_id_to_zyx
+
+CHECKPOINT_DIR = "voxel_feature_checkpoints"
+LSEG_DIR = "lseg_embed_features/features"
+CAM_PARAMS_ORIG = "camera_params/camera_params.json"
+VOXEL_PLY = "minkowski_grid.ply"
+MAX_IMAGES = 216                 # AGG:106
+DOWNSAMPLE_FACTOR = 0.5          # AGG:209
+CHECKPOINT_EVERY = 20            # AGG:318
+_NEVER = 2 ** 30
+
+
+class VoxelFeatureAggregator:
+    """Running per-voxel aggregate over views, resident on one GPU."""
+
+    def __init__(self, occ_zyx, grid_origin, voxel_size, channels, mode="parity", device="cuda"):
+        self.dev = torch.device(device)
+        self.mode = mode
+        self.occ3 = occ_zyx.to(self.dev).contiguous()
+        self.occ = self.occ3.unsqueeze(0).long().contiguous()            # DPF:143
+        self.grid_origin = [float(v) for v in grid_origin]
+        self.voxel_size = float(voxel_size)
+        self.C = int(channels)
+        self.n_rows = int(self.occ3.max().item()) + 1                     # DPF:158-159
+        self.id_to_zyx = build_id_to_zyx(self.occ3)                       # DPF:35-45
+        self.valid_id = self.id_to_zyx[:, 0] != -1
+        self.ws = voxproj_host.Workspace()
+        self.n_seen = 0
+        n, C = self.n_rows, self.C
+        self.views = torch.zeros(n, dtype=torch.int32, device=self.dev)   # AGG voxel_hit_count
+        if mode == "parity":
+            self.run16 = torch.zeros(n, C, dtype=torch.float16, device=self.dev)   # AGG voxel_feature_sum (fp16)
+            self.first_view = torch.full((n,), _NEVER, dtype=torch.int32, device=self.dev)
+            self._cnt = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._sum = torch.zeros(n, C, dtype=torch.float32, device=self.dev)
+        else:
+            self.sum32 = torch.zeros(n, C, dtype=torch.float32, device=self.dev)
+            self.count = torch.zeros(n, dtype=torch.int32, device=self.dev)
+
+    def _opts(self, W, H):
+        return [float(W), float(H), 0.01, 10.0, float(np.float32(self.voxel_size * 0.5))]   # DPF:167-169
+
+    def add_views(self, feats, c2w, intr4):
+        """feats f32 [V,H,W,C] on the GPU, c2w f32 [V,4,4], intr4 f32 [4] (shared by the call's views)."""
+        V, H, W, C = feats.shape
+        assert C == self.C
+        feats = feats.contiguous()
+        intr = intr4.reshape(1, 4).to(self.dev, torch.float32).contiguous()
+        c2w = c2w.to(self.dev, torch.float32).contiguous()
+        if self.mode == "parity":
+            for v in range(V):
+                self._cnt.zero_()
+                self._sum.zero_()
+                voxproj_host.project_features_raw(feats[v:v + 1].unsqueeze(0), self.occ, c2w[v].reshape(-1), intr,
+                                                  self._opts(W, H), self._cnt, self._sum, self.grid_origin,
+                                                  self.voxel_size, workspace=self.ws, sync=True, reuse_accel=None)
+                hit = (self._cnt > 0) & self.valid_id                      # DPF:237,246-248
+                rows16 = self._sum.to(torch.float16)                       # DPF:252
+                first = hit & (self.views == 0)
+                again = hit & (self.views > 0)
+                # AGG:309-312: first time feat.clone(), afterwards an fp16 "+=" (float add rounded to half)
+                self.run16 = torch.where(first[:, None], rows16, self.run16)
+                self.run16 = torch.where(again[:, None], (self.run16.float() + rows16.float()).to(torch.float16), self.run16)
+                self.first_view = torch.where(first, torch.full_like(self.first_view, self.n_seen), self.first_view)
+                self.views += hit.to(torch.int32)                          # AGG:313
+                self.n_seen += 1
+        else:
+            # keep every argument of a pipelined call alive until the stream is drained
+            self._keep = getattr(self, "_keep", [])
+            vmi = c2w.reshape(-1)
+            self._keep.append((feats, vmi, intr))
+            voxproj_host.project_features_raw(feats.unsqueeze(0), self.occ, vmi, intr, self._opts(W, H), self.count,
+                                              self.sum32, self.grid_origin, self.voxel_size, workspace=self.ws,
+                                              sync=False, reuse_accel=None, pipeline=True, views_hit=self.views)
+            self.n_seen += V
+            if len(self._keep) > 4:
+                self.flush()
+
+    def flush(self):
+        if self.mode != "parity":
+            voxproj_host.workspace_status(self.ws, self.dev)
+            self._keep = []
+
+    def all_reduce(self):
+        """Combine the ranks' partial {sum, count, views} (fast mode; one RCCL all-reduce each)."""
+        import torch.distributed as dist
+        assert self.mode != "parity", "the parity mode is order-dependent (fp16 running sums) and stays on one GPU"
+        self.flush()
+        dist.all_reduce(self.sum32)
+        dist.all_reduce(self.count)
+        dist.all_reduce(self.views)
+        n = torch.tensor([self.n_seen], device=self.dev)
+        dist.all_reduce(n)
+        self.n_seen = int(n.item())
+
+    def result(self, xyz_dtype=np.float32):
+        """Consolidated tensors in the reference's schema (AGG:381-451)."""
+        self.flush()
+        if self.mode == "parity":
+            ids = torch.nonzero(self.views > 0).reshape(-1)
+            order = torch.argsort(self.first_view[ids].long() * self.n_rows + ids)      # dict insertion order
+            ids = ids[order]
+            avg = (self.run16[ids].float() / self.views[ids].float()[:, None]).to(torch.float16)   # AGG:385
+        else:
+            ids = torch.nonzero((self.views > 0) & self.valid_id).reshape(-1)
+            avg = (self.sum32[ids] / self.views[ids].float()[:, None]).to(torch.float16)
+        zyx = self.id_to_zyx[ids].cpu().numpy()
+        # AGG:404-407: np.array([x,y,z]) * VOXEL_SIZE + np.array(GRID_ORIGIN) in float64, stored as float32
+        xyz64 = zyx[:, [2, 1, 0]].astype(np.int64) * self.voxel_size + np.array(self.grid_origin, dtype=np.float64)
+        out = dict(xyz=torch.from_numpy(xyz64.astype(xyz_dtype)), avg_feats=avg.cpu(),
+                   voxel_coords=torch.from_numpy(zyx.astype(np.int32)),
+                   hit_count=self.views[ids].to(torch.int32).cpu())
+        if self.mode != "parity":
+            out.update(sum=self.sum32[ids].cpu(), count=self.count[ids].cpu(), voxel_ids=ids.to(torch.int32).cpu())
+        return out
+
+
+def _image_size(entry, cams, images_dir, name):
+    """(H_orig, W_orig) of a view: the reference reads the image file (AGG:210-214); the camera JSON's
+    width/height are used when the image is not there."""
+    if images_dir:
+        for ext in (".jpg", ".jpeg", ".png", ".JPG", ".JPEG", ".PNG", ""):
+            p = os.path.join(images_dir, name + ext)
+            if os.path.exists(p):
+                from PIL import Image
+                with Image.open(p) as im:
+                    return im.height, im.width
+    cam = cams[str(entry["camera_id"])]
+    return int(cam["height"]), int(cam["width"])
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Aggregate voxel features pipeline")
+    ap.add_argument("--first_only", action="store_true", help="Only process the first input image for debug")
+    ap.add_argument("--mode", choices=("parity", "fast"), default="parity")
+    ap.add_argument("--lseg_dir", default=os.environ.get("LSEG_DIR", LSEG_DIR))
+    ap.add_argument("--cam_params", default=os.environ.get("CAM_PARAMS_ORIG", CAM_PARAMS_ORIG))
+    ap.add_argument("--voxel_ply", default=os.environ.get("VOXEL_PLY", VOXEL_PLY))
+    ap.add_argument("--images_dir", default=os.environ.get("IMAGES_DIR", ""))
+    ap.add_argument("--checkpoint_dir", default=os.environ.get("CHECKPOINT_DIR", CHECKPOINT_DIR))
+    ap.add_argument("--max_images", type=int, default=MAX_IMAGES)
+    ap.add_argument("--downsample_factor", type=float, default=DOWNSAMPLE_FACTOR)
+    ap.add_argument("--views_per_call", type=int, default=8, help="fast mode: views per projector call")
+    args = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        assert args.mode == "fast", "multi-GPU aggregation needs --mode fast"
+        dist.init_process_group("nccl", device_id=dev)
+    os.makedirs(args.checkpoint_dir, exist_ok=True)
+
+    voxel_size, grid_origin, grid_shape, n_from_name = bso.extract_voxel_params(args.voxel_ply)   # AGG:92
+    num_voxels = n_from_name if n_from_name is not None else (int(np.prod(grid_shape)) if grid_shape else "unknown")
+    feature_files = sorted(glob.glob(os.path.join(args.lseg_dir, "*.npy")))                       # AGG:101
+    if not feature_files:
+        raise RuntimeError(f"No .npy feature files found in {args.lseg_dir}")
+    feature_files = feature_files[:args.max_images]
+    if args.first_only:
+        feature_files = feature_files[:1]
+    occ = bso.build_occupancy(bso.read_voxel_ply(args.voxel_ply), grid_origin, voxel_size, device=dev)   # AGG:118-127
+    by_name, cams = ptd.load_camera_params(args.cam_params)
+
+    agg, idx = None, 0
+    batch_f, batch_c, batch_intr = [], [], None
+    mine = feature_files[rank::world]
+    for k, fpath in enumerate(mine):
+        name = os.path.basename(fpath)[:-4]
+        entry = by_name.get(name)
+        if entry is None:
+            print(f"[ERROR] No camera entry for {name}")
+            continue
+        H0, W0 = _image_size(entry, cams, args.images_dir, name)
+        H_new, W_new = int(H0 * args.downsample_factor), int(W0 * args.downsample_factor)          # AGG:215
+        feats = ptd.upsample_features(np.load(fpath), (H_new, W_new), device=dev)                  # PTD:115-127
+        intr, c2w = ptd.camera_for(entry, cams, args.downsample_factor)                            # PTD:132-172
+        if agg is None:
+            agg = VoxelFeatureAggregator(occ, grid_origin, voxel_size, feats.shape[-1], args.mode, dev)
+        same = batch_intr is not None and torch.equal(batch_intr, intr) and batch_f[0].shape == feats.shape
+        if batch_f and (not same or len(batch_f) >= (1 if args.mode == "parity" else args.views_per_call)):
+            agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
+            batch_f, batch_c = [], []
+        batch_f.append(feats)
+        batch_c.append(c2w)
+        batch_intr = intr
+        idx = k + 1
+        if args.mode == "parity" and idx % CHECKPOINT_EVERY == 0:                                  # AGG:318-352
+            agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
+            batch_f, batch_c = [], []
+            r = agg.result(xyz_dtype=np.float64)
+            torch.save({k2: r[k2] for k2 in ("xyz", "avg_feats", "hit_count", "voxel_coords")},
+                       os.path.join(args.checkpoint_dir, f"checkpoint_features_{idx}.pt"))
+            print(f"[CHECKPOINT] Saved consolidated checkpoint data after {idx} images")
+    if batch_f:
+        agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
+    if agg is None:
+        raise RuntimeError("no view could be processed")
+    if world > 1:
+        agg.all_reduce()
+    if rank == 0:
+        r = agg.result()
+        n_done = agg.n_seen
+        if r["xyz"].shape[0] == 0:
+            print("[DONE] No occupied voxels in final aggregation, skipping export.")
+        else:
+            save_path = os.path.join(args.checkpoint_dir, f"ALL_nonzero_voxel_features_{n_done}_vox{num_voxels}.pt")
+            torch.save({"xyz": r["xyz"], "avg_feats": r["avg_feats"], "voxel_coords": r["voxel_coords"]}, save_path)   # AGG:447-451
+            print(f"[PT] Saved filtered and compressed voxel data (xyz, features, coords) as: {save_path}")
+            if args.mode == "fast":
+                torch.save(r, save_path[:-3] + "_fp32.pt")
+        print(f"[DONE] PROJECTION PIPELINE COMPLETED. Checkpoint directory: {args.checkpoint_dir}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

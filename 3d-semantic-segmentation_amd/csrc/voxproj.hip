@@ -744,6 +744,7 @@ struct GatherArgs {
     const int *n_heavy;
     int heavy_t;
     int *count;
+    int *views_hit;          // nullable: += number of views of this call in which the voxel got >= 1 pixel
     float *out;
     int *status;
 };
@@ -824,7 +825,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
         float *orow = g.out + (long long)id * C + cb;
         acc_load<K, VEC>(acc, orow, cb, C, lane);
         const Acc<K, VEC> acc0 = acc;
-        int found = 0;
+        int found = 0, nviews = 0;
         for (int b = 0; b < p.B && found < expected; b++) {
             float cxw, cyw, czw;
             if (!voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
@@ -841,7 +842,9 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
                     const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
                     const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
                     const long long bv = (long long)b * p.V + vbase + l;
+                    const int before = found;
                     scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
+                    nviews += found > before;
                 }
             }
         }
@@ -851,11 +854,18 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
             if (lane == 0 && cb == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
             acc = acc0;
             found = 0;
-            for (long long bv = 0; bv < (long long)p.B * p.V; bv++)
+            nviews = 0;
+            for (long long bv = 0; bv < (long long)p.B * p.V; bv++) {
+                const int before = found;
                 scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
+                nviews += found > before;
+            }
         }
         acc_store<K, VEC>(acc, orow, cb, C, lane);
-        if (cb == 0 && lane == 0) g.count[id] += found;   // K.cu:77 (one add of the per-call total)
+        if (cb == 0 && lane == 0) {
+            g.count[id] += found;   // K.cu:77 (one add of the per-call total)
+            if (g.views_hit) g.views_hit[id] += nviews;
+        }
     }
 }
 
@@ -875,7 +885,7 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
     const float zn = near_plane(p);
     constexpr int CB = 64 * K * VEC;
     constexpr int R = (CB + GW * 64 - 1) / (GW * 64);   // running-sum channels per thread
-    int found_total = 0;
+    int found_total = 0, nviews = 0;
     for (int cb = 0; cb < C; cb += CB) {
         float run[R];
         float *orow = g.out + (long long)id * C + cb;
@@ -885,6 +895,7 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
             run[r] = (c < CB && cb + c < C) ? orow[c] : 0.f;
         }
         found_total = 0;
+        nviews = 0;
         for (int b = 0; b < p.B && found_total < expected; b++) {
             float cxw = 0.f, cyw = 0.f, czw = 0.f;
             if (!whole_image && !voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
@@ -927,8 +938,11 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
                             for (int ww = 0; ww < GW; ww++) run[r] += part[ww][c];
                         }
                     }
+                    int fview = 0;
 #pragma unroll
-                    for (int ww = 0; ww < GW; ww++) found_total += part_found[ww];
+                    for (int ww = 0; ww < GW; ww++) fview += part_found[ww];
+                    found_total += fview;
+                    nviews += fview > 0;
                     __syncthreads();
                 }
             }
@@ -940,7 +954,10 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
             if (c < CB && cb + c < C) orow[c] = run[r];
         }
     }
-    if (tid == 0) g.count[id] += found_total;
+    if (tid == 0) {
+        g.count[id] += found_total;
+        if (g.views_hit) g.views_hit[id] += nviews;
+    }
     return true;
 }
 
@@ -973,6 +990,57 @@ __global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RGB path (BASELINE config 5): the reference's debug_project_colors.py:54-81 is a per-voxel Python loop --
+// voxel-driven, nearest pixel, NO occlusion test, numpy float64 arithmetic.  One lane per grid cell; an
+// occupied cell walks the views in order, so each voxel's float32 colour sum is accumulated in view order
+// exactly like aggregate_voxel_colors_onthefly.py:134-140 does (one contribution per view, no atomics).
+// Arithmetic contract: oracle_rgb_project in oracle/projector_oracle.c (separate multiplies and adds in
+// float64, IEEE divide, round-half-even).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ occ, int dimz, int dimy, int dimx,
+                                                        const float *__restrict__ c2w, const float *__restrict__ intr,
+                                                        int V, float ox, float oy, float oz, double vs,
+                                                        const unsigned char *__restrict__ img, int img_h, int img_w,
+                                                        float *color_sum, int *hit_count, int *first_view,
+                                                        long long n_rows, int view_base, int *status)
+{
+    const long long cells = (long long)dimz * dimy * dimx;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const int id = occ[i];
+    if (id <= 0) return;                                  // DPC:50 (occ > 0)
+    if (id >= n_rows) { atomicOr(&status[ST_BADID], 1); return; }
+    const int z = (int)(i / ((long long)dimy * dimx));
+    const int r = (int)(i - (long long)z * dimy * dimx);
+    const int y = r / dimx, x = r - y * dimx;
+    const double wx = (double)ox + vs * (double)x, wy = (double)oy + vs * (double)y, wz = (double)oz + vs * (double)z;   // DPC:60
+    float sr = color_sum[(long long)id * 3 + 0], sg = color_sum[(long long)id * 3 + 1], sb = color_sum[(long long)id * 3 + 2];
+    int hc = hit_count[id];
+    int fv = first_view ? first_view[id] : 0;
+    for (int v = 0; v < V; v++) {
+        const float *m = c2w + (long long)v * 16;
+        const double dx = wx - (double)m[3], dy = wy - (double)m[7], dz = wz - (double)m[11];                  // DPC:61-63
+        const double cx = (double)m[0] * dx + (double)m[4] * dy + (double)m[8] * dz;                            // R^T d
+        const double cy = (double)m[1] * dx + (double)m[5] * dy + (double)m[9] * dz;
+        const double cz = (double)m[2] * dx + (double)m[6] * dy + (double)m[10] * dz;
+        if (!(cz > 0.0)) continue;                                                                              // DPC:65
+        const double u = (double)intr[v * 4 + 0] * (cx / cz) + (double)intr[v * 4 + 2];                         // DPC:66-67
+        const double w = (double)intr[v * 4 + 1] * (cy / cz) + (double)intr[v * 4 + 3];
+        const double ur = rint(u), vr = rint(w);                                                                // DPC:68 (half to even)
+        if (!(ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h)) continue;                    // DPC:69
+        const unsigned char *px = img + (((long long)v * img_h + (int)vr) * img_w + (int)ur) * 3;
+        sr += (float)((double)px[0] / 255.0);                                                                   // DPC:70,75; AGGC:139
+        sg += (float)((double)px[1] / 255.0);
+        sb += (float)((double)px[2] / 255.0);
+        hc += 1;                                                                                                // AGGC:140
+        fv = min(fv, view_base + v);
+    }
+    color_sum[(long long)id * 3 + 0] = sr; color_sum[(long long)id * 3 + 1] = sg; color_sum[(long long)id * 3 + 2] = sb;
+    hit_count[id] = hc;
+    if (first_view) first_view[id] = fv;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -992,7 +1060,7 @@ size_t vp_workspace_bytes(int B, int V, int H, int W, int C, int dimz, int dimy,
 }
 
 int vp_project_features(const float *feats, const int64_t *occ, const float *vmi, const float *intr,
-                        const float *opts_host, int32_t *count, float *out,
+                        const float *opts_host, int32_t *count, float *out, int32_t *views_hit,
                         const float *grid_origin_host, float voxel_size,
                         int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows,
                         void *workspace, size_t workspace_bytes, void *stream_, int flags)
@@ -1125,7 +1193,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     GatherArgs g;
     g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
-    g.heavy_t = heavy_t; g.count = count; g.out = out; g.status = status;
+    g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
     const int blocks_h = 128;
@@ -1257,6 +1325,31 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
     }
     VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + off, size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    return VP_OK;
+}
+
+int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx, const float *c2w, const float *intr,
+                      int V, const float *grid_origin_host, double voxel_size, const uint8_t *images,
+                      int img_h, int img_w, float *color_sum, int32_t *hit_count, int32_t *first_view,
+                      int64_t n_rows, int view_base, int32_t *status_dev, void *stream_)
+{
+    if (!occ || !c2w || !intr || !grid_origin_host || !images || !color_sum || !hit_count || !status_dev)
+        return fail(VP_EINVAL, "null pointer argument");
+    if (dimz <= 0 || dimy <= 0 || dimx <= 0 || V <= 0 || img_h <= 0 || img_w <= 0 || n_rows <= 0)
+        return fail(VP_EINVAL, "non-positive dimension");
+    const long long cells = (long long)dimz * dimy * dimx;
+    if (cells >= (1ll << 31)) return fail(VP_EINVAL, "occupancy grid has >= 2^31 cells");
+    hipStream_t stream = (hipStream_t)stream_;
+    VP_HIP(hipMemsetAsync(status_dev, 0, ST_WORDS * sizeof(int), stream));
+    hipLaunchKernelGGL(k_project_colors, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, (const int *)occ,
+                       dimz, dimy, dimx, c2w, intr, V, grid_origin_host[0], grid_origin_host[1], grid_origin_host[2],
+                       voxel_size, (const unsigned char *)images, img_h, img_w, color_sum, (int *)hit_count,
+                       (int *)first_view, (long long)n_rows, view_base, (int *)status_dev);
+    VP_HIP(hipGetLastError());
+    int st[ST_WORDS];
+    VP_HIP(hipMemcpyAsync(st, status_dev, sizeof(st), hipMemcpyDeviceToHost, stream));
+    VP_HIP(hipStreamSynchronize(stream));
+    if (st[ST_BADID]) return fail(VP_EBADID, "an occupancy ID is outside [1, n_rows): outputs are too small for the grid's IDs");
     return VP_OK;
 }
 

@@ -1,0 +1,111 @@
+"""Per-view tensor packing (counterpart of the reference's prepare_tensor_data.py).
+
+The reference script (cuda_project_image_to_sparse_voxel/prepare_tensor_data.py:38-201) turns LSeg
+feature files + COLMAP-style camera JSON into ``tensor_data.pt``.  This module keeps its command line
+and the keys/shapes/dtypes of that file, and exposes the steps as functions so that the aggregator can
+call them in-process:
+
+  load_camera_params   JSON schema of PTD:56-72  ({"images": {id: {name, camera_id, R, tvec}}, "cameras":
+                       {id: {params: [fx,fy,cx,cy] | [f,cx,cy]}}})
+  camera_for           intrinsics x downsample factor (PTD:132-143) and c2w = [R^T | -R^T t] (PTD:165-172)
+  upsample_features    fp16 [C,h,w] -> bilinear (half-pixel centres, like cv2.INTER_LINEAR, PTD:119-127) ->
+                       cast back to the file's dtype (PTD:126) -> float32 channels-last [H,W,C] (PTD:152,183-185)
+
+The resize runs as one torch ``interpolate`` (on the GPU when given a CUDA device) instead of C separate
+``cv2.resize`` calls; cv2 is third-party and unpinned in the reference (cuda_requirement.txt), so its exact
+float rounding is not part of the parity contract -- the feature tensor handed to the projector is.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+
+def load_camera_params(path):
+    with open(path, "r") as f:
+        cam_params = json.load(f)
+    imgs, cams = cam_params["images"], cam_params["cameras"]
+    by_name = {}
+    for _, v in (imgs.items() if isinstance(imgs, dict) else enumerate(imgs)):
+        if isinstance(v, dict) and "name" in v:
+            by_name[v["name"]] = v
+    return by_name, cams
+
+
+def camera_for(entry, cams, downsample_factor=None):
+    """(intr float32 [4] = fx,fy,cx,cy, c2w float32 [4,4]) of one image entry."""
+    params = cams[str(entry["camera_id"])]["params"]
+    if len(params) == 4:
+        fx, fy, cx, cy = params
+    else:
+        fx, cx, cy = params
+        fy = fx
+    if downsample_factor is not None:
+        fx, fy, cx, cy = (v * downsample_factor for v in (fx, fy, cx, cy))
+    intr = torch.tensor([fx, fy, cx, cy], dtype=torch.float32)
+    R = np.array(entry["R"], dtype=np.float32)
+    t = np.array(entry["tvec"], dtype=np.float32)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = R.T
+    c2w[:3, 3] = -R.T @ t
+    return intr, torch.from_numpy(c2w)
+
+
+def upsample_features(arr, size=None, device="cpu"):
+    """[C,h,w] array (any float dtype) -> float32 [H,W,C] tensor on ``device``."""
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    if size is not None and tuple(t.shape[1:]) != tuple(size):
+        up = torch.nn.functional.interpolate(t.float()[None], size=tuple(size), mode="bilinear", align_corners=False)[0]
+        t = up.to(t.dtype)                       # PTD:126  arr_upsampled.astype(arr.dtype)
+    return t.float().permute(1, 2, 0).contiguous()
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--lseg_dir", required=True)
+    p.add_argument("--scaled_camera_params", required=True)
+    p.add_argument("--occupancy", required=True)
+    p.add_argument("--voxel_size", type=float, required=True)
+    p.add_argument("--grid_origin", nargs=3, type=float, required=True)
+    p.add_argument("--max_images", type=int, default=10)
+    p.add_argument("--output", required=True)
+    p.add_argument("--image_size", nargs=2, type=int)
+    p.add_argument("--downsample_factor", type=float, default=None)
+    args = p.parse_args(argv)
+
+    occ = torch.load(args.occupancy)
+    by_name, cams = load_camera_params(args.scaled_camera_params)
+    files = sorted(f for f in os.listdir(args.lseg_dir) if f.endswith(".npy"))
+    if args.max_images:
+        files = files[:args.max_images]
+    feats, intrs, exts = [], [], []
+    for fname in files:
+        entry = by_name.get(fname[:-4])
+        if entry is None:
+            print(f"[WARN] No camera entry for feature file: {fname}, skipping.")
+            continue
+        arr = np.load(os.path.join(args.lseg_dir, fname))
+        feats.append(upsample_features(arr, tuple(args.image_size) if args.image_size else None))
+        intr, c2w = camera_for(entry, cams, args.downsample_factor)
+        intrs.append(intr)
+        if args.downsample_factor is not None:      # PTD:143 and :162 both append
+            intrs.append(camera_for(entry, cams, None)[0])
+        exts.append(c2w)
+    if not feats:
+        raise RuntimeError("No valid feature/camera pairs found!")
+    out = {
+        "encoded_2d_features": torch.stack(feats, 0).unsqueeze(0),           # [1,V,H,W,C]
+        "occupancy_3D": occ,
+        "intrinsicParams": torch.stack(intrs, 0).unsqueeze(0),
+        "viewMatrixInv": torch.stack(exts, 0).unsqueeze(0),
+        "grid_origin": torch.tensor(args.grid_origin, dtype=torch.float32),
+        "voxel_size": float(args.voxel_size),
+    }
+    torch.save(out, args.output)
+    print(f"Saved tensor_data to: {args.output}")
+
+
+if __name__ == "__main__":
+    main()

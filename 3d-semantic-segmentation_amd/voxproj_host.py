@@ -24,7 +24,7 @@ _lock = threading.Lock()
 EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
-    "vp_profile_enable", "vp_profile_read", "vp_workspace_release",
+    "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors",
 ]
 
 
@@ -59,7 +59,7 @@ def lib():
             vp = ctypes.c_void_p
             L.vp_project_features.restype = ctypes.c_int
             L.vp_project_features.argtypes = [
-                vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), vp, vp, ctypes.POINTER(ctypes.c_float),
+                vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), vp, vp, vp, ctypes.POINTER(ctypes.c_float),
                 ctypes.c_float] + [ctypes.c_int] * 8 + [ctypes.c_int64, vp, ctypes.c_size_t, vp, ctypes.c_int]
             L.vp_workspace_status.restype = ctypes.c_int
             L.vp_workspace_status.argtypes = [vp, vp]
@@ -73,6 +73,10 @@ def lib():
             L.vp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
             L.vp_workspace_release.restype = ctypes.c_int
             L.vp_workspace_release.argtypes = [vp]
+            L.vp_project_colors.restype = ctypes.c_int
+            L.vp_project_colors.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_float), ctypes.c_double, vp, ctypes.c_int,
+                                            ctypes.c_int, vp, vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp]
             _lib = L
     return _lib
 
@@ -135,7 +139,8 @@ def get_workspace(device):
 
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
-                         workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False):
+                         workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False,
+                         views_hit=None):
     """Call vp_project_features on torch CUDA tensors (already validated by the caller).
 
     opts5 / grid_origin3 are python sequences of floats.  Returns the Workspace used.
@@ -145,7 +150,8 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     again; True/False = force.  ``exact_march``: evaluate every ray sample (A/B arm of the leaping march;
     default from env VOXPROJ_EXACT_MARCH).  ``pipeline``: asynchronous job mode (VP_FLAG_PIPELINE): phase 1 of
     this call overlaps the previous call's gather; the caller must keep occ/vmi/intr alive and unchanged
-    until ``workspace_status`` (or a device synchronise) and must not pass sync.
+    until ``workspace_status`` (or a device synchronise) and must not pass sync.  ``views_hit``: optional
+    int32 [n_rows] tensor, += number of views of this call that hit each voxel.
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -169,7 +175,8 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     with torch.cuda.device(feats.device):
         rc = lib().vp_project_features(
             feats.data_ptr(), occ.data_ptr(), vmi.data_ptr(), intr.data_ptr(), o,
-            count.data_ptr(), out.data_ptr(), g, ctypes.c_float(float(voxel_size)),
+            count.data_ptr(), out.data_ptr(), views_hit.data_ptr() if views_hit is not None else None,
+            g, ctypes.c_float(float(voxel_size)),
             B, V, H, W, C, dimz, dimy, dimx, n_rows, ptr, ws.capacity(), stream, flags)
     if rc != VP_OK:
         ws.accel_key = None
@@ -220,3 +227,28 @@ def workspace_status(ws, device):
     import torch
     stream = torch.cuda.current_stream(device).cuda_stream
     check(lib().vp_workspace_status(ws.ptr(), stream))
+
+
+def project_colors_raw(occ_zyx, c2w, intr, grid_origin3, voxel_size, images, color_sum, hit_count, first_view=None,
+                       view_base=0):
+    """vp_project_colors on torch CUDA tensors: occ i32 [Z,Y,X], c2w f32 [V,4,4], intr f32 [V,4],
+    images u8 [V,H,W,3]; color_sum f32 [n_rows,3], hit_count i32 [n_rows], first_view i32 [n_rows] or None."""
+    import torch
+    dev = occ_zyx.device
+    assert occ_zyx.is_cuda and occ_zyx.dtype == torch.int32 and occ_zyx.is_contiguous()
+    V = int(images.shape[0])
+    assert images.dtype == torch.uint8 and images.is_contiguous() and images.shape[-1] == 3
+    assert c2w.dtype == torch.float32 and c2w.is_contiguous() and c2w.numel() == V * 16
+    assert intr.dtype == torch.float32 and intr.is_contiguous() and intr.numel() == V * 4
+    assert color_sum.dtype == torch.float32 and color_sum.is_contiguous() and hit_count.dtype == torch.int32
+    n_rows = int(hit_count.shape[0])
+    status = torch.zeros(64, dtype=torch.int32, device=dev)
+    g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
+    Z, Y, X = occ_zyx.shape
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        check(lib().vp_project_colors(
+            occ_zyx.data_ptr(), Z, Y, X, c2w.data_ptr(), intr.data_ptr(), V, g, ctypes.c_double(float(voxel_size)),
+            images.data_ptr(), int(images.shape[1]), int(images.shape[2]), color_sum.data_ptr(), hit_count.data_ptr(),
+            first_view.data_ptr() if first_view is not None else None, n_rows, int(view_base), status.data_ptr(),
+            stream))

@@ -76,6 +76,9 @@ size_t vp_workspace_bytes(int B, int V, int H, int W, int C,
  *   opts_host    f32 [5] HOST = width, height, depthMin, depthMax, rayIncrement (K.cu:400-407)
  *   count        i32 [n_rows]   in/out, count[id] += #pixels        (K.cu:77)
  *   out          f32 [n_rows,C] in/out, out[id,:] += feature rows   (K.cu:85-91)
+ *   views_hit    i32 [n_rows]   in/out or NULL, += number of views of this call in which the voxel
+ *                received at least one pixel -- the aggregator's "hit_count" (AGG:313 counts VIEWS,
+ *                one per debug_project_features run), so that multi-view calls can feed it
  *   grid_origin_host f32 [3] HOST                                  (K.cu:412-413)
  *   voxel_size                                                     (K.cu:414)
  *   workspace    device scratch of >= vp_workspace_bytes(...) bytes, 256-byte aligned
@@ -88,7 +91,7 @@ size_t vp_workspace_bytes(int B, int V, int H, int W, int C,
  */
 int vp_project_features(const float *feats, const int64_t *occ, const float *vmi,
                         const float *intr, const float *opts_host,
-                        int32_t *count, float *out,
+                        int32_t *count, float *out, int32_t *views_hit,
                         const float *grid_origin_host, float voxel_size,
                         int B, int V, int H, int W, int C,
                         int dimz, int dimy, int dimx, int64_t n_rows,
@@ -121,6 +124,29 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
  */
 int vp_profile_enable(int on);
 int vp_profile_read(double *ms4, int64_t *launches4);
+
+/*
+ * RGB path: replaces the per-voxel Python loop of DPC:54-81 plus the per-view accumulation of
+ * aggregate_voxel_colors_onthefly.py:134-140 for a batch of V views (voxel-driven, nearest pixel, no
+ * occlusion test, float64 arithmetic exactly as numpy promotes it there).
+ *
+ *   occ        i32 [dimz,dimy,dimx] device, > 0 = voxel ID (BSO:44-46; DPC:50 tests occ > 0)
+ *   c2w        f32 [V,16] device, row-major camera->world (DPC:61-62 reads R and t from it)
+ *   intr       f32 [V,4] device, fx fy cx cy of each view (DPC:64)
+ *   images     u8  [V,img_h,img_w,3] device (DPC:52,70)
+ *   color_sum  f32 [n_rows,3] in/out: += img[v,u]/255 for every view that sees the voxel (AGGC:139)
+ *   hit_count  i32 [n_rows]   in/out: += number of such views (AGGC:140)
+ *   first_view i32 [n_rows]   in/out or NULL: min(view_base + v) over those views -- reproduces the
+ *                             dict insertion order of AGGC:136-137 on the host
+ *   status_dev i32 [64] device scratch
+ * Synchronous (returns after the stream has drained).
+ */
+int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx,
+                      const float *c2w, const float *intr, int V,
+                      const float *grid_origin_host, double voxel_size,
+                      const uint8_t *images, int img_h, int img_w,
+                      float *color_sum, int32_t *hit_count, int32_t *first_view,
+                      int64_t n_rows, int view_base, int32_t *status_dev, void *stream);
 
 /*
  * Forgets the side stream / events the library keeps for a workspace that was used with
