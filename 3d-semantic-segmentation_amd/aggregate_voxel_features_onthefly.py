@@ -123,12 +123,10 @@ class VoxelFeatureAggregator:
         """Combine the ranks' partial {sum, count, views} (fast mode; one RCCL all-reduce each)."""
         import torch.distributed as dist
         assert self.mode != "parity", "the parity mode is order-dependent (fp16 running sums) and stays on one GPU"
+        from view_sharding import reduce_partials
         self.flush()
-        dist.all_reduce(self.sum32)
-        dist.all_reduce(self.count)
-        dist.all_reduce(self.views)
         n = torch.tensor([self.n_seen], device=self.dev)
-        dist.all_reduce(n)
+        reduce_partials(dist, [self.sum32, self.count, self.views, n])
         self.n_seen = int(n.item())
 
     def result(self, xyz_dtype=np.float32):
@@ -203,7 +201,8 @@ def main(argv=None):
 
     agg, idx = None, 0
     batch_f, batch_c, batch_intr = [], [], None
-    mine = feature_files[rank::world]
+    from view_sharding import views_of_rank
+    mine = [feature_files[i] for i in views_of_rank(len(feature_files), rank, world)]
     for k, fpath in enumerate(mine):
         name = os.path.basename(fpath)[:-4]
         entry = by_name.get(name)

@@ -141,6 +141,7 @@ PipeState *pipe_state(void *workspace, bool create)
         if (kv.first == workspace) return kv.second;
     if (!create) return nullptr;
     PipeState *ps = new PipeState();
+    // (a high-priority side stream was measured: no effect on the pipelined step time, so plain streams)
     bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ps->side2, hipStreamNonBlocking) == hipSuccess;
     for (int q = 0; q < 2 && ok; q++)

@@ -97,7 +97,8 @@ def main():
     if a.views:
         n_views = a.views
     scene = make_scene(n_vox, n_views, W, H, seed=0)
-    my_views = list(range(rank, n_views, world))
+    from view_sharding import reduce_partials, views_of_rank
+    my_views = views_of_rank(n_views, rank, world)
     chunk = max(1, min(a.chunk, len(my_views)))
     pool = max(chunk, (min(a.pool, len(my_views)) // chunk) * chunk)
 
@@ -135,8 +136,7 @@ def main():
         for ci in range(len(calls)):
             one_call(ci)
         if dist is not None:
-            dist.all_reduce(out)
-            dist.all_reduce(count)
+            reduce_partials(dist, [out, count])
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px = 0, 0, 0, {}, 0
