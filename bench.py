@@ -56,6 +56,22 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(workload, chunk):
+    """HBM bytes per k_gather launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json),
+    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
+    None unless the profile was taken on this workload / views-per-call."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+    except OSError:
+        return None
+    if prof.get("workload") != workload or prof.get("views_per_call") != chunk:
+        return None
+    g = prof["k_gather"]
+    return int((2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024)
+
+
 def cpu_baseline(scene, C, n_views, n_threads):
     """Time the CPU oracle (port of project_image_cuda_kernel.cu:24-92,157-187) on n_views views."""
     from oracle import oracle
@@ -209,7 +225,8 @@ def main():
                                   "overlapped": pipeline},
             "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(a.workload, chunk) if (not a.views and world == 1) else None,
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline:
