@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="plain calls: phase 1 and 2 serial on one stream")
     ap.add_argument("--cpu-views", type=int, default=2, help="views in the cpu_baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
+                    "the multi-rank code path on a single-GPU box (together with --single-device)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -99,12 +102,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the projector has no CPU fallback")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", 0 if a.single_device else local)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend)
 
     import voxproj_host
     from synthetic_scene import make_features_torch, make_scene

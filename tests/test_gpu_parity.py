@@ -304,3 +304,65 @@ def test_full_resolution_view_properties(oracle_mod):
     m.project_features_cuda(*args)
     assert torch.equal(count_t.long(), 2 * torch.bincount(flat, minlength=n_rows) * (torch.arange(n_rows, device=DEV) > 0))
     assert ((out_t.double().sum(0) - 2 * tot_px).abs() <= 2e-6 * tot_abs).all()
+
+
+def test_far_from_origin_disables_leaping_but_stays_exact(oracle_mod):
+    # world coordinates ~1e6 voxel sizes from zero: fp32 positions are too coarse for the leap bound, the kernel
+    # must fall back to evaluating every sample (leap_ok = false) and still match the oracle bit for bit
+    s = make_scene(2000, 2, 40, 24, seed=51, room=(5.0, 4.0, 2.4))
+    shift = np.array([30000.0, -20000.0, 10000.0], np.float32)
+    c2w = s.c2w.copy()
+    c2w[:, :3, 3] += shift
+    feats = make_features_np(2, 24, 40, 8, seed=51)[None]
+    r, _, _ = _compare(oracle_mod, feats, s.occ[None], c2w, s.intr, s.opts(), s.grid_origin + shift, s.voxel_size,
+                       s.n_vox + 1)
+    assert (r["hits"] > 0).mean() > 0.3
+
+
+def test_degenerate_and_scaled_poses(oracle_mod):
+    # view 0: singular camera matrix (all rays collapse; the search box falls back to whole images);
+    # view 1: non-rigid pose (anisotropic scale + shear) -- the box uses the true inverse, rays are the reference's
+    s = make_scene(2000, 3, 40, 24, seed=52, room=(5.0, 4.0, 2.4))
+    c2w = s.c2w.copy()
+    c2w[0, :3, :3] = 0.0
+    c2w[0, 0, 2] = 1.0                                   # rank-1: every direction maps onto +x
+    c2w[1, :3, :3] = c2w[1, :3, :3] @ np.array([[1.3, 0.2, 0.0], [0.0, 0.8, 0.1], [0.0, 0.0, 1.1]], np.float32)
+    feats = make_features_np(3, 24, 40, 8, seed=52)[None]
+    _compare(oracle_mod, feats, s.occ[None], c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+
+
+def test_zero_depth_min_and_coarse_steps(oracle_mod):
+    s = make_scene(2000, 2, 40, 24, seed=53, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(2, 24, 40, 8, seed=53)[None]
+    for opts in (np.array([40, 24, 0.0, 10.0, 0.5 * s.voxel_size], np.float32),        # dmin = 0: t starts at 0
+                 np.array([40, 24, 0.01, 3.0, 2.7 * s.voxel_size], np.float32),        # steps longer than a voxel
+                 np.array([40, 24, 0.5, 2.0, 0.013 * s.voxel_size], np.float32)):      # very fine steps, short range
+        _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, opts, s.grid_origin, s.voxel_size, s.n_vox + 1)
+
+
+def test_image_sizes_not_multiples_of_the_tiles(oracle_mod):
+    for (W, H) in ((1, 1), (7, 3), (17, 33), (65, 9)):
+        s = make_scene(2000, 2, W, H, seed=54, room=(5.0, 4.0, 2.4))
+        feats = make_features_np(2, H, W, 4, seed=54)[None]
+        _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+
+
+def test_camera_inside_and_next_to_voxels(oracle_mod):
+    # cameras sitting on the wall / inside an occupied block: cubes straddle the near plane, boxes are clipped
+    s = make_scene(2000, 4, 40, 24, seed=55, room=(5.0, 4.0, 2.4))
+    c2w = s.c2w.copy()
+    c2w[0, :3, 3] = s.points[100] + np.float32(0.3 * s.voxel_size)
+    c2w[1, :3, 3] = s.points[900] - np.float32(0.6 * s.voxel_size)
+    c2w[2, 2, 3] = s.grid_origin[2] + np.float32(1.2 * s.voxel_size)     # just above the floor
+    feats = make_features_np(4, 24, 40, 8, seed=55)[None]
+    r, _, _ = _compare(oracle_mod, feats, s.occ[None], c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+
+
+def test_march_ab_arm_exact_loop_equals_leaping(oracle_mod, monkeypatch):
+    s = make_scene(2000, 2, 40, 24, seed=56, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(2, 24, 40, 8, seed=56)[None]
+    monkeypatch.setenv("VOXPROJ_EXACT_MARCH", "1")
+    _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+    monkeypatch.delenv("VOXPROJ_EXACT_MARCH")
+    monkeypatch.setenv("VOXPROJ_NO_LDS_DIST", "1")
+    _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
