@@ -116,6 +116,11 @@ struct PipeState {
     bool used[2] = {false, false};
     long long calls = 0;
     int last_q = 0;
+    // fused mode: the call whose phase 1 has been launched and whose gather is still owed
+    bool pending = false;
+    struct GatherArgs *pend_g = nullptr;
+    struct Params *pend_p = nullptr;
+    bool pend_vec_ok = false;
 };
 // offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
 std::vector<std::pair<const void *, size_t>> g_last_hit;
@@ -166,7 +171,7 @@ struct Params {
     long long n_rows;
 };
 
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_WORDS = 64 };
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_TILE = 3, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
@@ -418,30 +423,37 @@ __global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
 // ------------------------------------------------------------------------------------------------
 // MODE 0: reference loop; 1: leaping march, distance field read through L2; 2: leaping march with the
 // block distance field staged in LDS by the workgroup (32x32-pixel workgroups, two per CU).
-template <int MODE, int WX, int WY>
-__global__ __launch_bounds__(64 * WX * WY) void k_first_hit(const long long *__restrict__ occ,
-                                                   const float *__restrict__ vmi,
-                                                   const float *__restrict__ intr, Params p,
-                                                   const ulonglong2 *__restrict__ near2,
-                                                   const unsigned char *__restrict__ dist,
-                                                   int nby, int nbx, long long nblk,
-                                                   int *__restrict__ hit, int *cnt_call, int *heavy_list,
-                                                   int heavy_t, int *status)
+struct FirstHitArgs {
+    const long long *occ;
+    const float *vmi;
+    const float *intr;
+    const ulonglong2 *near2;
+    const unsigned char *dist;
+    int nby, nbx;
+    long long nblk;
+    int *hit;
+    int *cnt_call;
+    int *heavy_list;
+    int heavy_t;
+    int *status;
+};
+
+template <int MODE>
+__device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Params &p, int x, int y, int bv,
+                                               unsigned char *lds_dist)
 {
     constexpr bool ACCEL = MODE != 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dist[];
-    const int bv = blockIdx.z;
+    const long long *__restrict__ occ = fa.occ;
+    const float *__restrict__ vmi = fa.vmi;
+    const float *__restrict__ intr = fa.intr;
+    const ulonglong2 *__restrict__ near2 = fa.near2;
+    const unsigned char *__restrict__ dist = fa.dist;
+    const int nby = fa.nby, nbx = fa.nbx;
+    const long long nblk = fa.nblk;
+    int *__restrict__ hit = fa.hit;
+    int *cnt_call = fa.cnt_call, *heavy_list = fa.heavy_list, *status = fa.status;
+    const int heavy_t = fa.heavy_t;
     const int b = bv / p.V;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x * (8 * WX) + (wave % WX) * 8 + (lane & 7);
-    const int y = blockIdx.y * (8 * WY) + (wave / WX) * 8 + (lane >> 3);
-    if constexpr (MODE == 2) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(dist + (long long)b * nblk);   // 256-byte aligned per batch
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_dist);
-        const int n16 = (int)((nblk + 15) >> 4);
-        for (int i = threadIdx.x; i < n16; i += 64 * WX * WY) dst[i] = src[i];
-        __syncthreads();
-    }
     if (x >= p.width || y >= p.height) return;
 
     const float *m = vmi + (long long)bv * 16;           // K.cu:178-179 (row-major float4x4)
@@ -576,9 +588,62 @@ __global__ __launch_bounds__(64 * WX * WY) void k_first_hit(const long long *__r
         id = 0;
     }
     hit[((long long)bv * p.height + y) * p.width + x] = id;
-    if (id != 0) {
-        // the pixel that lifts a voxel's per-call count above heavy_t enlists it for the heavy role
-        if (atomicAdd(&cnt_call[id], 1) == heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = id;
+    // Per-call hit histogram, aggregated per wavefront: the lanes of an 8x8 tile share a handful of voxel IDs, so
+    // one lane per distinct ID adds the whole group (returning integer atomics on hot addresses were measured to
+    // slow a concurrently running gather 3-4x; this issues ~8x fewer of them).  The add that lifts a voxel's
+    // per-call count above heavy_t enlists it for the workgroup path.
+    {
+        const int lane_ = threadIdx.x & 63;
+        unsigned long long todo = __ballot(id != 0);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            const int cur = __builtin_amdgcn_readlane(id, l);
+            const unsigned long long m = __ballot(id == cur);
+            if (lane_ == l) {
+                const int n = __popcll(m);
+                const int old = atomicAdd(&cnt_call[cur], n);
+                if (old <= heavy_t && old + n > heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = cur;
+            }
+            todo &= ~m;
+        }
+    }
+}
+
+template <int MODE, int WX, int WY>
+__global__ __launch_bounds__(64 * WX * WY) void k_first_hit(FirstHitArgs fa, Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dist[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = blockIdx.x * (8 * WX) + (wave % WX) * 8 + (lane & 7);
+    const int y = blockIdx.y * (8 * WY) + (wave / WX) * 8 + (lane >> 3);
+    const int bv = blockIdx.z;
+    if constexpr (MODE == 2) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(fa.dist + (long long)(bv / p.V) * fa.nblk);   // 256-byte aligned per batch
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_dist);
+        const int n16 = (int)((fa.nblk + 15) >> 4);
+        for (int i = threadIdx.x; i < n16; i += 64 * WX * WY) dst[i] = src[i];
+        __syncthreads();
+    }
+    first_hit_body<MODE>(fa, p, x, y, bv, lds_dist);
+}
+
+// Persistent form for the pipelined mode: a fixed number of workgroups whose wavefronts pull 8x8-pixel tiles
+// from an atomic counter until none are left (the counter only grows, so every wave reaches the exit).  Run
+// beside the gather it keeps a fixed, small number of march waves on every CU instead of fighting the
+// gather's short-lived workgroups for placement.
+__global__ __launch_bounds__(256) void k_first_hit_workers(FirstHitArgs fa, Params p, int tiles_x, int tiles_y,
+                                                           int n_tiles, int *tile_counter)
+{
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = atomicAdd(tile_counter, 1);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= n_tiles) return;
+        const int bv = tile / (tiles_x * tiles_y);
+        const int r = tile - bv * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        first_hit_body<1>(fa, p, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), bv, nullptr);
     }
 }
 
@@ -965,6 +1030,10 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
 template <int K, int VEC, int U>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
+    // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
+    // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
+    // march waves of the next call that share the SIMD in pipelined mode.
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const long long idl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
     if (idl >= p.n_rows) return;
@@ -989,6 +1058,38 @@ __global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p
             gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
         }
     }
+}
+
+// Fused pipeline step: ONE launch holds the gather of call j and the ray-march of call j+1.  The first
+// `n_workers` workgroups are persistent march workers: each wavefront pulls 8x8-pixel tiles from an atomic
+// counter until none are left (every wave reaches the exit: the counter only grows).  They are dispatched
+// first, so each CU keeps a fixed small number of issue-bound march waves while the HBM-bound gather
+// workgroups behind them in the grid fill the remaining slots.  (Two concurrent streams, and a plain
+// 1:1 interleave of march and gather workgroups, were both measured to starve the gather of wave slots.)
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(256) void k_fused(GatherArgs g, Params pg, FirstHitArgs fa, Params pf, int n_workers,
+                                               int tiles_x, int tiles_y, int n_tiles, int *tile_counter)
+{
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < n_workers) {
+        for (;;) {
+            int tile = 0;
+            if (lane == 0) tile = atomicAdd(tile_counter, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            if (tile >= n_tiles) return;
+            const int bv = tile / (tiles_x * tiles_y);
+            const int r = tile - bv * (tiles_x * tiles_y);
+            const int ty = r / tiles_x, tx = r - ty * tiles_x;
+            first_hit_body<1>(fa, pf, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), bv, nullptr);
+        }
+    }
+    const long long gi = (long long)blockIdx.x - n_workers;
+    const long long idl = gi * 4 + (threadIdx.x >> 6) + 1;
+    if (idl >= pg.n_rows) return;
+    const int id = (int)idl;
+    const int expected = g.cnt_call[id];
+    if (expected == 0 || expected > g.heavy_t) return;
+    gather_voxel_wave<K, VEC, U>(g, pg, id, expected, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1042,7 +1143,74 @@ __global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ 
     if (first_view) first_view[id] = fv;
 }
 
+// diagnostic co-runner (tools/dbg_corun.py): mode 0 = pure VALU, 1 = dependent scattered L2 loads,
+// 2 = returning int atomics on a small table
+__global__ __launch_bounds__(256) void k_debug_spin(int mode, int iters, const int *table, int table_n, int *sink)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    float a = (float)tid * 1e-3f, b = 1.0001f;
+    int idx = tid % table_n;
+    int acc = 0;
+    for (int i = 0; i < iters; i++) {
+        if (mode == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) a = a * b + 0.5f;
+        } else if (mode == 1) {
+            idx = (table[idx] + tid + i * 97) % table_n;
+            acc += idx;
+        } else {
+            acc += atomicAdd(&sink[64 + (idx % 4096)], 1);
+            idx = (idx * 31 + 7) % table_n;
+        }
+    }
+    if (a == 12345.678f || acc == 0x7fffffff) sink[0] = 1;
+}
+
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+#define VP_DISPATCH_KVU(KERNEL, VEC_OK, C, ...)                                   \
+    do {                                                                          \
+        if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), __VA_ARGS__); \
+        else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
+    } while (0)
+
+constexpr int HEAVY_BLOCKS = 128;
+
+// heavy-voxel kernel + plain gather of one call on `stream`
+int launch_gather(const GatherArgs &g, const Params &p, bool vec_ok, size_t glds, hipStream_t stream)
+{
+    const int blocks_n = (int)((p.n_rows - 1 + 3) / 4);
+    {
+        ProfSpan sp; sp.begin(3, stream);
+        VP_DISPATCH_KVU(k_gather_heavy, vec_ok, p.C, dim3(HEAVY_BLOCKS), dim3(GW * 64), 0, stream, g, p);
+        sp.end();
+    }
+    if (blocks_n > 0) {
+        ProfSpan sp; sp.begin(2, stream);
+        VP_DISPATCH_KVU(k_gather, vec_ok, p.C, dim3(blocks_n), dim3(256), glds, stream, g, p);
+        sp.end();
+    }
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+// fused mode: launch the gather that is still owed for the last pipelined call on this workspace
+int flush_pending(PipeState *ps, hipStream_t stream)
+{
+    if (!ps || !ps->pending) return VP_OK;
+    ps->pending = false;
+    return launch_gather(*ps->pend_g, *ps->pend_p, ps->pend_vec_ok, 0, stream);
+}
+
+bool fused_mode()
+{
+    const char *e = getenv("VOXPROJ_PIPE");
+    return e && strcmp(e, "fused") == 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
@@ -1097,11 +1265,17 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     const bool pipe = (flags & VP_FLAG_PIPELINE) != 0;
     PipeState *ps = pipe_state(workspace, pipe);
     if (pipe && !ps) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
+    const bool fused = pipe && fused_mode();
     int q = 0;
     hipStream_t s1 = s0;
-    if (pipe) {
+    if (fused) {
+        q = (int)(ps->calls & 1);
+    } else if (pipe) {
+        { int rc_ = flush_pending(ps, s0); if (rc_ != VP_OK) return rc_; }
         q = (int)(ps->calls & 1);
         s1 = ps->side;
+    } else if (ps && ps->pending) {
+        { int rc_ = flush_pending(ps, s0); if (rc_ != VP_OK) return rc_; }
     } else if (ps && (ps->used[0] || ps->used[1])) {
         // a plain call after pipelined ones on this workspace: drain the side stream first
         VP_HIP(hipStreamSynchronize(ps->side));
@@ -1122,7 +1296,10 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
 
     if (!(flags & VP_FLAG_REUSE_ACCEL)) {
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
-        if (pipe) {
+        if (fused) {
+            int rc_ = flush_pending(ps, s0);
+            if (rc_ != VP_OK) return rc_;
+        } else if (pipe) {
             VP_HIP(hipStreamSynchronize(ps->side));
             VP_HIP(hipStreamSynchronize(ps->side2));
             VP_HIP(hipStreamSynchronize(s0));
@@ -1142,10 +1319,10 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
         hipLaunchKernelGGL(k_build_near, dim3((unsigned)((near_waves + 3) / 4)), dim3(256), 0, s0, mask64, (const unsigned char *)dist,
                            near2, dimz, dimy, dimx, l.nbz, l.nby, l.nbx, l.nblk, B);
         sp.end();
-        if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
+        if (pipe && !fused) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
     }
 
-    if (pipe) {
+    if (pipe && !fused) {
         VP_HIP(hipEventRecord(ps->entry, s0));
         // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
         if (ps->used[q]) VP_HIP(hipStreamWaitEvent(s1, ps->call_done[q], 0));
@@ -1162,13 +1339,28 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
         hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
         sp.end();
     }
-    {
+    FirstHitArgs fa;
+    fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
+    fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
+    fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status;
+    if (!fused) {
         ProfSpan sp; sp.begin(1, s1);
-#define FH_ARGS (const long long *)occ, vmi, intr, p, near2, dist, l.nby, l.nbx, l.nblk, hit, cnt_call, heavy_list, heavy_t, status
+#define FH_ARGS fa, p
         const size_t lds_bytes = (size_t(l.nblk) + 15) & ~size_t(15);
-        const bool lds_ok = lds_bytes <= 80 * 1024 && !getenv("VOXPROJ_NO_LDS_DIST");
+        // Variants kept for A/B runs: distance field staged in LDS by 32x32-pixel workgroups
+        // (VOXPROJ_LDS_DIST=1) and persistent tile workers (VOXPROJ_FH_WORKERS=n).  Measured on R2 the plain
+        // 16x16-pixel grid reading the tables through L2 is the fastest both alone and beside the gather.
+        const bool lds_ok = lds_bytes <= 80 * 1024 && getenv("VOXPROJ_LDS_DIST");
+        int n_workers = 0;
+        if (const char *e = getenv("VOXPROJ_FH_WORKERS")) n_workers = atoi(e);
         if (flags & VP_FLAG_EXACT_MARCH) {
             hipLaunchKernelGGL((k_first_hit<0, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, s1, FH_ARGS);
+        } else if (pipe && n_workers > 0) {
+            const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+            const long long n_tiles = (long long)tiles_x * tiles_y * B * V;
+            if (n_tiles >= (1ll << 31)) return fail(VP_EINVAL, "too many pixel tiles");
+            hipLaunchKernelGGL(k_first_hit_workers, dim3(n_workers), dim3(256), 0, s1, fa, p, tiles_x, tiles_y, (int)n_tiles,
+                               status + ST_TILE);
         } else if (lds_ok) {
             static bool attr_set = false;
             if (!attr_set) {
@@ -1188,7 +1380,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
 #undef FH_ARGS
         sp.end();
     }
-    if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
+    if (pipe && !fused) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
 
     // ---- phase 2 ----
     GatherArgs g;
@@ -1196,12 +1388,47 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    if (fused) {
+        // one launch: gather of the previous pipelined call (if any) + ray-march of this one
+        const int fgx = (W + 15) / 16, fgy = (H + 15) / 16;
+        if (ps->pending) {
+            const GatherArgs &pg = *ps->pend_g;
+            const Params &pp = *ps->pend_p;
+            {
+                ProfSpan sp; sp.begin(3, s0);
+                VP_DISPATCH_KVU(k_gather_heavy, ps->pend_vec_ok, pp.C, dim3(HEAVY_BLOCKS), dim3(GW * 64), 0, s0, pg, pp);
+                sp.end();
+            }
+            const long long n_g = (pp.n_rows - 1 + 3) / 4;
+            int n_workers = 512;                 // 2 workgroups (8 march waves) per CU on 256 CUs
+            if (const char *e = getenv("VOXPROJ_FH_WORKERS")) n_workers = atoi(e) > 0 ? atoi(e) : n_workers;
+            const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+            const long long n_tiles = (long long)tiles_x * tiles_y * B * V;
+            if (n_g + n_workers >= (1ll << 31) || n_tiles >= (1ll << 31)) return fail(VP_EINVAL, "grid too large");
+            ProfSpan sp; sp.begin(2, s0);
+            VP_DISPATCH_KVU(k_fused, ps->pend_vec_ok, pp.C, dim3((unsigned)(n_g + n_workers)), dim3(256), 0, s0, pg, pp,
+                            fa, p, n_workers, tiles_x, tiles_y, (int)n_tiles, status + ST_TILE);
+            sp.end();
+        } else {
+            ProfSpan sp; sp.begin(1, s0);
+            hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3(fgx, fgy, B * V), dim3(256), 0, s0, fa, p);
+            sp.end();
+        }
+        if (!ps->pend_g) { ps->pend_g = new GatherArgs(); ps->pend_p = new Params(); }
+        *ps->pend_g = g;
+        *ps->pend_p = p;
+        ps->pend_vec_ok = vec_ok;
+        ps->pending = true;
+        ps->last_q = q;
+        ps->calls++;
+        VP_HIP(hipGetLastError());
+        return VP_OK;
+    }
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
     const int blocks_h = 128;
-    // Occupancy shaping for the pipelined mode: the gather is HBM-bound and loses <2 % at 12-16 wavefronts per
-    // CU (measured), so it reserves 40 KiB of LDS per workgroup (= at most 4 workgroups, 16 wavefronts per CU) and
-    // leaves the other wave slots to the ray-march of the next call running beside it.
-    size_t glds = pipe ? 40 * 1024 : 0;
+    // A/B knob: a dynamic-LDS reservation caps the gather's workgroups per CU (no gain measured once the
+    // march's atomics were aggregated; default off).
+    size_t glds = 0;
     if (const char *e = getenv("VOXPROJ_GATHER_LDS_KB")) glds = size_t(atoi(e)) * 1024;
 #define LAUNCH_GATHER(KERNEL, BLOCKS, THREADS, STREAM)                                              \
     do {                                                                                            \
@@ -1254,12 +1481,28 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
 static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WORDS] */)
 {
     if (PipeState *ps = pipe_state(workspace, false)) {
+        int rc_ = flush_pending(ps, stream);
+        if (rc_ != VP_OK) return rc_;
         VP_HIP(hipStreamSynchronize(ps->side));
         VP_HIP(hipStreamSynchronize(ps->side2));
     }
     VP_HIP(hipMemcpyAsync(st, workspace, 2 * align256(ST_WORDS * sizeof(int)), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
     return VP_OK;
+}
+
+int vp_debug_spin(int mode, int blocks, int iters, const int32_t *table, int table_n, int32_t *sink, void *stream_)
+{
+    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, mode, iters, (const int *)table,
+                       table_n, (int *)sink);
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int vp_workspace_flush(void *workspace, void *stream_)
+{
+    if (!workspace) return fail(VP_EINVAL, "null workspace");
+    return flush_pending(pipe_state(workspace, false), (hipStream_t)stream_);
 }
 
 int vp_workspace_status(void *workspace, void *stream_)
@@ -1270,7 +1513,7 @@ int vp_workspace_status(void *workspace, void *stream_)
     int rc = read_status(workspace, (hipStream_t)stream_, st);
     if (rc != VP_OK) return rc;
     PipeState *ps = pipe_state(workspace, false);
-    const bool second = ps && ps->used[1];
+    const bool second = ps && (ps->used[1] || ps->calls > 1);
     if (st[ST_BADID] || (second && st[ST_WORDS + ST_BADID]))
         return fail(VP_EBADID, "a ray hit an occupancy ID outside [1, n_rows): outputs are too small for the grid's IDs");
     return VP_OK;
@@ -1360,6 +1603,7 @@ int vp_workspace_release(void *workspace)
     for (size_t i = 0; i < g_pipes.size(); i++)
         if (g_pipes[i].first == workspace) {
             PipeState *ps = g_pipes[i].second;
+            if (ps->pending) (void)flush_pending(ps, nullptr);   // callers should have drained via vp_workspace_status
             (void)hipStreamSynchronize(ps->side);
             (void)hipStreamSynchronize(ps->side2);
             (void)hipStreamDestroy(ps->side);
@@ -1370,6 +1614,8 @@ int vp_workspace_release(void *workspace)
                 (void)hipEventDestroy(ps->call_done[q]);
             }
             (void)hipEventDestroy(ps->entry);
+            delete ps->pend_g;
+            delete ps->pend_p;
             delete ps;
             g_pipes.erase(g_pipes.begin() + i);
             break;

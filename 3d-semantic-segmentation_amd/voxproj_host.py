@@ -24,7 +24,8 @@ _lock = threading.Lock()
 EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
-    "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors",
+    "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors", "vp_workspace_flush",
+    "vp_debug_spin",
 ]
 
 
@@ -63,6 +64,8 @@ def lib():
                 ctypes.c_float] + [ctypes.c_int] * 8 + [ctypes.c_int64, vp, ctypes.c_size_t, vp, ctypes.c_int]
             L.vp_workspace_status.restype = ctypes.c_int
             L.vp_workspace_status.argtypes = [vp, vp]
+            L.vp_workspace_flush.restype = ctypes.c_int
+            L.vp_workspace_flush.argtypes = [vp, vp]
             L.vp_workspace_counters.restype = ctypes.c_int
             L.vp_workspace_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, vp]
             L.vp_copy_hit_image.restype = ctypes.c_int
@@ -104,6 +107,11 @@ class Workspace:
     def ensure(self, nbytes, device):
         import torch
         if self.buf is None or self.buf.numel() < nbytes + 256 or self.buf.device != device:
+            if self.buf is not None:
+                # growing while pipelined calls are in flight: finish them (the last call's gather may still
+                # be owed) before the old buffer goes away
+                import torch as _t
+                check(lib().vp_workspace_status(self.ptr(), _t.cuda.current_stream(self.buf.device).cuda_stream))
             self.release()
             self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
             self.accel_key = None
@@ -220,6 +228,13 @@ def profile_read():
     return dict(prep_ms=ms[0], first_hit_ms=ms[1], gather_ms=ms[2], heavy_ms=ms[3],
                 prep_launches=int(n[0]), first_hit_launches=int(n[1]), gather_launches=int(n[2]),
                 heavy_launches=int(n[3]))
+
+
+def workspace_flush(ws, device):
+    """Pipelined mode: launch the gather still owed by the last call (asynchronous, stream-ordered)."""
+    import torch
+    if ws.buf is not None:
+        check(lib().vp_workspace_flush(ws.ptr(), torch.cuda.current_stream(device).cuda_stream))
 
 
 def workspace_status(ws, device):

@@ -364,5 +364,5 @@ def test_march_ab_arm_exact_loop_equals_leaping(oracle_mod, monkeypatch):
     monkeypatch.setenv("VOXPROJ_EXACT_MARCH", "1")
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
     monkeypatch.delenv("VOXPROJ_EXACT_MARCH")
-    monkeypatch.setenv("VOXPROJ_NO_LDS_DIST", "1")
+    monkeypatch.setenv("VOXPROJ_LDS_DIST", "1")
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
