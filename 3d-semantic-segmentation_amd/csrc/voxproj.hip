@@ -244,39 +244,15 @@ __device__ __forceinline__ int f2i_sat(float v)
     return (int)v;
 }
 
-// J repetitions of t = fl(t + inc), computed without J dependent additions.
-// While t stays inside one binade [T, 2T), T = 2^e > inc, every addition rounds to the same grid of spacing
-// u = ulp(T): fl(t + inc) = t + g with g = inc rounded to a multiple of u (unless inc lies exactly half-way
-// between two multiples, where round-to-even depends on t; that binade is stepped one addition at a time).
-// g = fl(T + inc) - T.  Let m be the largest count with t + m*g <= 2T - u: for each of those m steps the exact
-// sum t_i + inc is below 2T, so the result is t_i + g, and t + m*g is exactly representable.  m is the floor
-// of an IEEE quotient of two multiples of u, which cannot round across an integer ("closed-form
-// leap").  The step that crosses the binade edge is one real addition.  All operations are IEEE binary32.
-__device__ __forceinline__ float advance_steps(float t, float inc, int J, float tEnd)
-{
-    while (J > 0 && t < tEnd) {
-        const unsigned eb = __float_as_uint(t) & 0x7f800000u;
-        const float T = __uint_as_float(eb);
-        const float T2 = __uint_as_float(eb + (1u << 23));
-        const float u = __uint_as_float(eb - (23u << 23));
-        const float g = (T + inc) - T;
-        const float r = inc - g;
-        bool fast = (eb >= (30u << 23)) && (eb < (0xfeu << 23)) && (inc < T) && (g > 0.0f) && (fabsf(r) * 2.0f != u);
-        int m = 0;
-        if (fast) {
-            const float A = (T2 - u) - t;
-            m = min(J, (int)floorf(A / g));
-        }
-        if (m > 0) {
-            t = t + (float)m * g;
-            J -= m;
-        } else {
-            t += inc;
-            J -= 1;
-        }
-    }
-    return t;
-}
+// Closed-form advance of the ray parameter (used inside k_first_hit): J repetitions of t = fl(t + inc) without J
+// dependent additions.  While t stays inside one binade [T, 2T), T = 2^e > inc, every addition rounds to the same
+// grid of spacing u = ulp(T): fl(t + inc) = t + g with g = inc rounded to a multiple of u (unless inc lies exactly
+// half-way between two multiples, where round-to-even depends on t; that binade is stepped one addition at a
+// time).  g = fl(T + inc) - T.  For any m <= floor(((2T - u) - t) / g) each of the m exact sums t_i + inc stays
+// below 2T, so every step adds exactly g, and t + m*g (a multiple of u below 2T) is exactly representable: one
+// multiply and one add reproduce m additions.  m may be under-estimated (reciprocal scaled by 0.999999) -- the
+// remaining steps are then taken by real additions; the addition that crosses the binade edge is always a real
+// one.  All operations are IEEE binary32; tests compare 530k full-resolution rays with the oracle's plain loop.
 
 // ------------------------------------------------------------------------------------------------
 // occupancy-derived tables (built once per occupancy grid, see VP_FLAG_REUSE_ACCEL):
@@ -512,18 +488,22 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
         const float span = (fabsf(cpx) + fabsf(cpy) + fabsf(cpz) + fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(tEnd)) * fabsf(rvs);
         const bool leap_ok = (span < 131072.0f) & (fabsf(tEnd) < 1.0e5f * fabsf(p.inc)) & (dcell == dcell) & (dcell < 1.0e6f);
         const float inv_dcell = leap_ok ? 0.999f / dcell : 0.0f;
-        int cur_blk = -1, cur_d = 0;
+        // cell index from the product q = (p-o)*(1/vs) when |q - rint(q)| < thr: |q| <= span along the whole ray, so
+        // thr = 0.5 - 2^-21*span keeps q and the IEEE quotient on the same side of every rounding boundary
+        const float thr = leap_ok ? 0.5f - span * 0x1p-21f : -1.0f;
+        unsigned cur_blk = 0xffffffffu;
+        int cur_d = 0;
         unsigned long long cur_lo = 0ull, cur_hi = 0ull;
         int dbg_leap = 0, dbg_fine = 0;
+        // binade cache of the closed-form t advance (see advance_steps): valid while t < bT2
+        float bT2 = 0.0f, bTu = 0.0f, bg = 0.0f, brg = 0.0f;
         while (t < tEnd) {
             const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
             const float ax = px - p.ox, ay = py - p.oy, az = pz - p.oz;
             const float qx = ax * rvs, qy = ay * rvs, qz = az * rvs;
             const float rx = rintf(qx), ry = rintf(qy), rz = rintf(qz);
-            const bool safe = (fabsf(qx - rx) < __builtin_fmaf(fabsf(qx), -0x1p-21f, 0.5f)) &
-                              (fabsf(qy - ry) < __builtin_fmaf(fabsf(qy), -0x1p-21f, 0.5f)) &
-                              (fabsf(qz - rz) < __builtin_fmaf(fabsf(qz), -0x1p-21f, 0.5f));
-            int ix = (int)rx, iy = (int)ry, iz = (int)rz;   // exact when safe (|q| < 2^20)
+            const bool safe = (fabsf(qx - rx) < thr) & (fabsf(qy - ry) < thr) & (fabsf(qz - rz) < thr);
+            int ix = (int)rx, iy = (int)ry, iz = (int)rz;   // exact when safe (|q| < 2^17)
             if (__builtin_expect(!safe, 0)) {
                 ix = f2i_sat(round_half_away(ax / p.vs));
                 iy = f2i_sat(round_half_away(ay / p.vs));
@@ -532,14 +512,13 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
             int D = 0;   // lower bound on the Chebyshev cell distance from (ix,iy,iz) to an occupied cell
             const bool ing = ((unsigned)ix < (unsigned)p.dimx) & ((unsigned)iy < (unsigned)p.dimy) & ((unsigned)iz < (unsigned)p.dimz);
             if (__builtin_expect(ing, 1)) {
-                const int blk = ((iz >> 2) * nby + (iy >> 2)) * nbx + (ix >> 2);
+                const unsigned blk = ((unsigned)(iz >> 2) * (unsigned)nby + (unsigned)(iy >> 2)) * (unsigned)nbx + (unsigned)(ix >> 2);
                 if (blk != cur_blk) {
                     cur_blk = blk;
+                    // both table reads go out together (the bit planes are only meaningful when cur_d <= 1)
+                    const ulonglong2 n2 = near_b[blk];
                     cur_d = (MODE == 2) ? lds_dist[blk] : dist_b[blk];
-                    if (cur_d <= 1) {
-                        const ulonglong2 n2 = near_b[blk];
-                        cur_lo = n2.x; cur_hi = n2.y;
-                    }
+                    cur_lo = n2.x; cur_hi = n2.y;
                 }
                 const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
                 const int nd = (int)((cur_lo >> bit) & 1ull) | ((int)((cur_hi >> bit) & 1ull) << 1);
@@ -567,16 +546,30 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                 D = max(dbox, din - dbox);
             }
             if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
-            t += p.inc;
-            // skip the J = floor((D - 1.5) / dcell) samples that cannot reach an occupied cell
-            int J = D >= 2 ? (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f) : 0;
-            t = J > 0 ? t + p.inc : t;
-            t = J > 1 ? t + p.inc : t;
-            t = J > 2 ? t + p.inc : t;
-            t = J > 3 ? t + p.inc : t;
-            t = J > 4 ? t + p.inc : t;
-            t = J > 5 ? t + p.inc : t;
-            if (__builtin_expect(J > 6, 0)) t = advance_steps(t, p.inc, J - 6, tEnd);
+            // advance by 1 + J samples, J = floor((D - 1.5) / dcell) of them provably unable to reach an occupied
+            // cell; the running sum t is reproduced exactly by the closed form of advance_steps, with the binade
+            // constants cached across evaluations
+            int S = 1 + (D >= 2 ? (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f) : 0);
+            for (;;) {
+                if (t >= bT2) {
+                    const unsigned eb = __float_as_uint(t) & 0x7f800000u;
+                    const float T = __uint_as_float(eb);
+                    const float u = __uint_as_float(eb - (23u << 23));
+                    bT2 = __uint_as_float(eb + (1u << 23));
+                    bTu = bT2 - u;
+                    bg = (T + p.inc) - T;
+                    const float r = p.inc - bg;
+                    const bool fast = (eb >= (30u << 23)) & (eb < (0xfeu << 23)) & (p.inc < T) & (bg > 0.0f) & (fabsf(r) * 2.0f != u);
+                    brg = fast ? __builtin_amdgcn_rcpf(bg) * 0.999999f : 0.0f;   // under-estimate: m <= floor(A/g)
+                }
+                const int m = (int)fminf(fmaxf((bTu - t) * brg, 0.0f), (float)S);
+                t = t + (float)m * bg;
+                S -= m;
+                if (S <= 0) break;
+                t += p.inc;          // the addition that crosses the binade edge (or a binade stepped one by one)
+                S -= 1;
+                if (S <= 0 || !(t < tEnd)) break;
+            }
         }
         if (heavy_t < 0) {   // diagnostic build path (VOXPROJ_DEBUG_EVALS): per-ray evaluation counts instead of IDs
             hit[((long long)bv * p.height + y) * p.width + x] = (dbg_leap << 16) | dbg_fine;
