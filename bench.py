@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="plain calls: phase 1 and 2 serial on one stream")
-    ap.add_argument("--cpu-views", type=int, default=2, help="views in the cpu_baseline sample")
+    ap.add_argument("--cpu-views", type=int, default=4, help="views in the cpu_baseline sample")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")

@@ -366,3 +366,22 @@ def test_march_ab_arm_exact_loop_equals_leaping(oracle_mod, monkeypatch):
     monkeypatch.delenv("VOXPROJ_EXACT_MARCH")
     monkeypatch.setenv("VOXPROJ_LDS_DIST", "1")
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+
+
+def test_ray_parameter_closed_form_over_many_increments(oracle_mod):
+    # the march reproduces t += inc by a closed form per binade; sweep increments with awkward bit patterns
+    # (powers of two, one-bit / all-bits mantissas, increments larger than early t values) on a sparse grid where
+    # most rays run the whole [dmin, dmax) range through every binade
+    rng = np.random.default_rng(77)
+    occ = np.zeros((16, 24, 28), np.int32)
+    idx = rng.choice(occ.size, 150, replace=False)
+    occ.reshape(-1)[idx] = np.arange(1, 151)
+    s = make_scene(2000, 2, 24, 16, seed=78, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(2, 16, 24, 4, seed=79)[None]
+    incs = [0.125, 0.03125, np.float32(0.1), np.float32(1.0) / 3, np.float32(0.0625) + np.float32(2.0 ** -27),
+            np.float32(0.02) , np.float32(0.7), np.float32(2.5), np.float32(0.011111111)]
+    incs += [np.float32(v) for v in np.exp(rng.uniform(np.log(0.004), np.log(1.5), 8))]
+    for dmin, dmax in ((0.01, 10.0), (0.0, 33.0), (1e-4, 5.0)):
+        for inc in incs:
+            opts = np.array([24, 16, dmin, dmax, inc], np.float32)
+            _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, opts, np.array([-2.1, -1.7, 0.05], np.float32), 0.2, 151)
