@@ -691,9 +691,19 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
 #pragma unroll
                             for (int k = 0; k < K; k++) {
                                 const int ch = (k * 64 + lane) * 4;
+#ifndef VP_NO_NT   // feature rows are read exactly once: non-temporal loads keep them out of L2/MALL (+12 % measured)
+                                typedef float v4f_ __attribute__((ext_vector_type(4)));
+                                if (cb + ch < C) {
+                                    const v4f_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(fv + off[j] + ch));
+                                    r[j][k] = make_float4(t_.x, t_.y, t_.z, t_.w);
+                                } else {
+                                    r[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                }
+#else
                                 r[j][k] = (cb + ch < C)
                                               ? *reinterpret_cast<const float4 *>(fv + off[j] + ch)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                             }
                         }
 #pragma unroll
@@ -1164,9 +1174,12 @@ __global__ __launch_bounds__(256) void k_debug_spin(int mode, int iters, const i
 // ------------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------------
+#ifndef VP_U
+#define VP_U 4
+#endif
 #define VP_DISPATCH_KVU(KERNEL, VEC_OK, C, ...)                                   \
     do {                                                                          \
-        if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), __VA_ARGS__); \
+        if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, VP_U>), __VA_ARGS__); \
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)

@@ -10,7 +10,7 @@ import threading
 import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvoxproj.so")
+LIB_PATH = os.environ.get("VOXPROJ_LIB") or os.path.join(_HERE, "libvoxproj.so")
 
 VP_OK = 0
 VP_FLAG_SYNC = 1
