@@ -5,8 +5,8 @@ Workload (BASELINE.json metric config, "R2"): 200 000 occupied voxels x 300 view
 synthetic feature maps (SURVEY.md section 8d generator, seed 0).  One STEP = one pass of the hot path
 over the whole scene: every view's feature map is read from HBM exactly once, in calls of --chunk views
 through the C-ABI (vp_project_features), features already resident in HBM.  326 GB of feature maps do
-not fit one GPU, so a pool of --pool distinct maps (default 32 = 34.8 GB) is cycled; the rays, the
-voxel assignment and the bytes moved are those of 300 distinct views.
+not fit one GPU, so a pool of --pool distinct maps (default 32 = 34.8 GB, far beyond the 256 MiB Infinity
+Cache) is cycled; the rays, the voxel assignment and the bytes moved are those of 300 distinct views.
 
 Multi-GPU (torchrun, one rank per GPU): rank r projects views r::G of the same 300-view scene, then one
 RCCL all-reduce of the per-voxel {feature-sum f32 [N+1,512], hit-count i32 [N+1]} -- total work fixed,
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="R2", choices=sorted(WORKLOADS))
-    ap.add_argument("--chunk", type=int, default=16, help="views per vp_project_features call")
+    ap.add_argument("--chunk", type=int, default=32, help="views per vp_project_features call")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -62,7 +62,8 @@ def parse():
 def pmc_traffic(workload, chunk):
     """HBM bytes per k_gather launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json),
     corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
-    None unless the profile was taken on this workload / views-per-call."""
+    Returned per VIEW of a full launch (the caller scales by its average views per launch); None unless the
+    profile was taken on this workload / views-per-call."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
@@ -72,7 +73,7 @@ def pmc_traffic(workload, chunk):
     if prof.get("workload") != workload or prof.get("views_per_call") != chunk:
         return None
     g = prof["k_gather"]
-    return int((2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024)
+    return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / prof["views_per_call"]
 
 
 def cpu_baseline(scene, C, n_views, n_threads):
@@ -233,7 +234,8 @@ def main():
             "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(a.workload, chunk) if (not a.views and world == 1) else None,
+                         "traffic": (int(pmc_traffic(a.workload, chunk) * len(my_views) / len(calls))
+                                     if (not a.views and world == 1 and pmc_traffic(a.workload, chunk)) else None),
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline:
