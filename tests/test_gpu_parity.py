@@ -385,3 +385,37 @@ def test_ray_parameter_closed_form_over_many_increments(oracle_mod):
         for inc in incs:
             opts = np.array([24, 16, dmin, dmax, inc], np.float32)
             _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, opts, np.array([-2.1, -1.7, 0.05], np.float32), 0.2, 151)
+
+
+@pytest.mark.parametrize("env", [{"VOXPROJ_PIPE": "fused"}, {"VOXPROJ_FH_WORKERS": "64"}, {"VOXPROJ_LDS_DIST": "1"},
+                                 {"VOXPROJ_GATHER_LDS_KB": "40"}])
+def test_pipelining_ab_arms_stay_exact(oracle_mod, monkeypatch, env):
+    # the alternative pipelining structures kept for A/B measurements must give the same bits
+    import voxproj_host
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = make_scene(2000, 9, 48, 32, seed=71, room=(5.0, 4.0, 2.4))
+    C = 16
+    feats = make_features_np(9, 32, 48, C, seed=71)
+    n_rows = s.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    dev = torch.device(DEV)
+    feats_t = torch.from_numpy(feats[None]).to(dev)
+    occ_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+    c2w_t = torch.from_numpy(s.c2w).to(dev)
+    intr_t = torch.from_numpy(s.intr[None]).to(dev)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    ws = voxproj_host.Workspace()
+    splits = [(0, 5), (5, 6), (6, 9), (0, 9)]
+    vmis = [c2w_t[a:b].reshape(-1).contiguous() for a, b in splits]
+    for (a, b), vmi in zip(splits, vmis):
+        oracle_mod.project_features(feats[None, a:b], s.occ[None].astype(np.int64), s.c2w[a:b].reshape(-1), s.intr[None],
+                                    s.opts(), s.grid_origin, s.voxel_size, count, out)
+        voxproj_host.project_features_raw(feats_t[:, a:b], occ_t, vmi, intr_t, [float(v) for v in s.opts()], count_t, out_t,
+                                          [float(v) for v in s.grid_origin], s.voxel_size, workspace=ws, sync=False,
+                                          pipeline=True)
+    voxproj_host.workspace_status(ws, dev)
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    assert out_t.cpu().numpy().tobytes() == out.tobytes()
