@@ -120,7 +120,7 @@ struct PipeState {
     bool pending = false;
     struct GatherArgs *pend_g = nullptr;
     struct Params *pend_p = nullptr;
-    bool pend_vec_ok = false;
+    int pend_vec_ok = 0;
 };
 // offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
 std::vector<std::pair<const void *, size_t>> g_last_hit;
@@ -648,6 +648,15 @@ struct Acc {
     float a[K * VEC];
 };
 
+// VEC == 8 selects the fp16 feature-map mode (8 halves = 16 B per lane per chunk; values are widened exactly and
+// summed in fp32 in the same order, so the outputs equal the fp32 path's on the same data).  Feature pointers are
+// carried as `const float *`; this advances one by `elems` ELEMENTS of the mode's input type.
+template <int VEC>
+__device__ __forceinline__ const float *feat_ptr(const float *base, long long elems)
+{
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + elems * (VEC == 8 ? 2 : 4));
+}
+
 // Scan the pixel box [x0,x1]x[y0,y1] of one view's ID image for pixels whose first hit is `id`, in
 // raster order, and add their feature rows (channels cb .. cb+64*K*VEC) to acc.  64 lanes cover a
 // tile of tw x (64/tw) pixels, tw = smallest power of two >= box width (capped at 64), so tiles
@@ -683,7 +692,31 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
                         n = j + 1;
                     }
                 }
-                if constexpr (VEC == 4) {
+                if constexpr (VEC == 8) {
+                    typedef _Float16 v8h_ __attribute__((ext_vector_type(8)));
+                    v8h_ r[U][K];
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                const int ch = (k * 64 + lane) * 8;
+                                if (cb + ch < C)
+                                    r[j][k] = __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
+                                        reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2));
+                                else
+                                    r[j][k] = (v8h_)(_Float16)0;
+                            }
+                        }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++)
+#pragma unroll
+                                for (int e = 0; e < 8; e++) acc.a[k * 8 + e] += (float)r[j][k][e];
+                        }
+                } else if constexpr (VEC == 4) {
                     float4 r[U][K];
 #pragma unroll
                     for (int j = 0; j < U; j++)
@@ -825,7 +858,14 @@ __device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, in
 {
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if constexpr (VEC == 4) {
+        if constexpr (VEC == 8) {
+            const int ch = (k * 64 + lane) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc.a[k * 8 + h * 4 + 0] = o.x; acc.a[k * 8 + h * 4 + 1] = o.y; acc.a[k * 8 + h * 4 + 2] = o.z; acc.a[k * 8 + h * 4 + 3] = o.w;
+            }
+        } else if constexpr (VEC == 4) {
             const int ch = (k * 64 + lane) * 4;
             const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
             acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
@@ -841,7 +881,14 @@ __device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, i
 {
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        if constexpr (VEC == 4) {
+        if constexpr (VEC == 8) {
+            const int ch = (k * 64 + lane) * 8;
+            if (cb + ch < C) {
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    *reinterpret_cast<float4 *>(orow + ch + h * 4) = make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+            }
+        } else if constexpr (VEC == 4) {
             const int ch = (k * 64 + lane) * 4;
             if (cb + ch < C)
                 *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
@@ -912,7 +959,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
                     const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
                     const long long bv = (long long)b * p.V + vbase + l;
                     const int before = found;
-                    scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
+                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
                     nviews += found > before;
                 }
             }
@@ -926,7 +973,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
             nviews = 0;
             for (long long bv = 0; bv < (long long)p.B * p.V; bv++) {
                 const int before = found;
-                scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
+                scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
                 nviews += found > before;
             }
         }
@@ -988,14 +1035,20 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
                     for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
                     int f = 0;
                     if (ry0 <= ry1)
-                        scan_box<K, VEC, U>(g.feats + bv * HW * C, g.hit + bv * HW, W, C, id, bx0, ry0, bx1, ry1, cb, lane, acc, f);
+                        scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, ry0, bx1, ry1, cb, lane, acc, f);
 #pragma unroll
                     for (int k = 0; k < K; k++) {
-                        if constexpr (VEC == 4)
+                        if constexpr (VEC == 8) {
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+                                *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 8 + h * 4]) =
+                                    make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+                        } else if constexpr (VEC == 4) {
                             *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 4]) =
                                 make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
-                        else
+                        } else {
                             part[w][k * 64 + lane] = acc.a[k];
+                        }
                     }
                     if (lane == 0) part_found[w] = f;
                     __syncthreads();
@@ -1177,9 +1230,11 @@ __global__ __launch_bounds__(256) void k_debug_spin(int mode, int iters, const i
 #ifndef VP_U
 #define VP_U 4
 #endif
+// VEC_OK: 0 = scalar fp32 path, 1 = 16-byte vector fp32 path, 2 = fp16 feature maps
 #define VP_DISPATCH_KVU(KERNEL, VEC_OK, C, ...)                                   \
     do {                                                                          \
-        if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, VP_U>), __VA_ARGS__); \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((KERNEL<1, 8, VP_U>), __VA_ARGS__); \
+        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, VP_U>), __VA_ARGS__); \
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
@@ -1187,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_debug_spin(int mode, int iters, const i
 constexpr int HEAVY_BLOCKS = 128;
 
 // heavy-voxel kernel + plain gather of one call on `stream`
-int launch_gather(const GatherArgs &g, const Params &p, bool vec_ok, size_t glds, hipStream_t stream)
+int launch_gather(const GatherArgs &g, const Params &p, int vec_ok, size_t glds, hipStream_t stream)
 {
     const int blocks_n = (int)((p.n_rows - 1 + 3) / 4);
     {
@@ -1234,12 +1289,14 @@ size_t vp_workspace_bytes(int B, int V, int H, int W, int C, int dimz, int dimy,
     return make_layout(B, V, H, W, n_rows, dimz, dimy, dimx).total;
 }
 
-int vp_project_features(const float *feats, const int64_t *occ, const float *vmi, const float *intr,
+static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, const float *vmi, const float *intr,
                         const float *opts_host, int32_t *count, float *out, int32_t *views_hit,
                         const float *grid_origin_host, float voxel_size,
                         int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows,
                         void *workspace, size_t workspace_bytes, void *stream_, int flags)
 {
+    if (feats_f16 && (C % 8 != 0 || ((uintptr_t)feats & 15) != 0 || ((uintptr_t)out & 15) != 0))
+        return fail(VP_EINVAL, "fp16 feature maps need C %% 8 == 0 and 16-byte aligned feats/out");
     if (!feats || !occ || !vmi || !intr || !opts_host || !count || !out || !grid_origin_host || !workspace)
         return fail(VP_EINVAL, "null pointer argument");
     if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || C <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0 || n_rows <= 0)
@@ -1393,7 +1450,7 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
-    const bool vec_ok = (C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
     if (fused) {
         // one launch: gather of the previous pipelined call (if any) + ray-march of this one
         const int fgx = (W + 15) / 16, fgy = (H + 15) / 16;
@@ -1436,12 +1493,8 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     // march's atomics were aggregated; default off).
     size_t glds = 0;
     if (const char *e = getenv("VOXPROJ_GATHER_LDS_KB")) glds = size_t(atoi(e)) * 1024;
-#define LAUNCH_GATHER(KERNEL, BLOCKS, THREADS, STREAM)                                              \
-    do {                                                                                            \
-        if (vec_ok && C > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p); \
-        else if (vec_ok) hipLaunchKernelGGL((KERNEL<1, 4, 4>), dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p);       \
-        else hipLaunchKernelGGL((KERNEL<4, 1, 4>), dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p);                   \
-    } while (0)
+#define LAUNCH_GATHER(KERNEL, BLOCKS, THREADS, STREAM) \
+    VP_DISPATCH_KVU(KERNEL, vec_ok, C, dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p)
     if (pipe) {
         // heavy voxels on the side stream, next to the normal gather.  They write output rows, so they must
         // follow everything the caller queued before this call and the previous call's gather.
@@ -1482,6 +1535,27 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
     VP_HIP(hipGetLastError());
     if (flags & VP_FLAG_SYNC) return vp_workspace_status(workspace, stream_);
     return VP_OK;
+}
+
+int vp_project_features(const float *feats, const int64_t *occ, const float *vmi, const float *intr,
+                        const float *opts_host, int32_t *count, float *out, int32_t *views_hit,
+                        const float *grid_origin_host, float voxel_size,
+                        int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows,
+                        void *workspace, size_t workspace_bytes, void *stream_, int flags)
+{
+    return project_impl(feats, false, occ, vmi, intr, opts_host, count, out, views_hit, grid_origin_host, voxel_size,
+                        B, V, H, W, C, dimz, dimy, dimx, n_rows, workspace, workspace_bytes, stream_, flags);
+}
+
+int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const float *vmi, const float *intr,
+                            const float *opts_host, int32_t *count, float *out, int32_t *views_hit,
+                            const float *grid_origin_host, float voxel_size,
+                            int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows,
+                            void *workspace, size_t workspace_bytes, void *stream_, int flags)
+{
+    return project_impl((const float *)feats_f16, true, occ, vmi, intr, opts_host, count, out, views_hit,
+                        grid_origin_host, voxel_size, B, V, H, W, C, dimz, dimy, dimx, n_rows, workspace,
+                        workspace_bytes, stream_, flags);
 }
 
 static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WORDS] */)

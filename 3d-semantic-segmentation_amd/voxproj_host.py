@@ -25,7 +25,7 @@ EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
     "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors", "vp_workspace_flush",
-    "vp_debug_spin",
+    "vp_debug_spin", "vp_project_features_f16",
 ]
 
 
@@ -62,6 +62,8 @@ def lib():
             L.vp_project_features.argtypes = [
                 vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), vp, vp, vp, ctypes.POINTER(ctypes.c_float),
                 ctypes.c_float] + [ctypes.c_int] * 8 + [ctypes.c_int64, vp, ctypes.c_size_t, vp, ctypes.c_int]
+            L.vp_project_features_f16.restype = ctypes.c_int
+            L.vp_project_features_f16.argtypes = L.vp_project_features.argtypes
             L.vp_workspace_status.restype = ctypes.c_int
             L.vp_workspace_status.argtypes = [vp, vp]
             L.vp_workspace_flush.restype = ctypes.c_int
@@ -149,7 +151,8 @@ def get_workspace(device):
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
                          workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False,
                          views_hit=None):
-    """Call vp_project_features on torch CUDA tensors (already validated by the caller).
+    """Call vp_project_features (or vp_project_features_f16 when ``feats`` is float16) on torch CUDA tensors
+    (already validated by the caller).
 
     opts5 / grid_origin3 are python sequences of floats.  Returns the Workspace used.
     ``reuse_accel``: None = reuse the occupancy-derived tables only if ``occ`` is the very same (still
@@ -180,8 +183,9 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream
+    entry = lib().vp_project_features_f16 if feats.dtype == torch.float16 else lib().vp_project_features
     with torch.cuda.device(feats.device):
-        rc = lib().vp_project_features(
+        rc = entry(
             feats.data_ptr(), occ.data_ptr(), vmi.data_ptr(), intr.data_ptr(), o,
             count.data_ptr(), out.data_ptr(), views_hit.data_ptr() if views_hit is not None else None,
             g, ctypes.c_float(float(voxel_size)),

@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="plain calls: phase 1 and 2 serial on one stream")
     ap.add_argument("--cpu-views", type=int, default=4, help="views in the cpu_baseline sample")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f16"), help="feature-map storage type; f32 is the "
+                    "BASELINE metric config, f16 the lossless half-bandwidth mode of SURVEY 8f/n4 (extra, not the headline)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -125,8 +127,14 @@ def main():
     chunk = max(1, min(a.chunk, len(my_views)))
     pool = max(chunk, (min(a.pool, len(my_views)) // chunk) * chunk)
 
-    feats = torch.empty((1, pool, H, W, C), dtype=torch.float32, device=dev)
-    make_features_torch(pool, H, W, C, dev, seed=0, out=feats[0])
+    esize = 4 if a.dtype == "f32" else 2
+    if a.dtype == "f32":
+        feats = torch.empty((1, pool, H, W, C), dtype=torch.float32, device=dev)
+        make_features_torch(pool, H, W, C, dev, seed=0, out=feats[0])
+    else:
+        feats = torch.empty((1, pool, H, W, C), dtype=torch.float16, device=dev)
+        for v in range(pool):
+            feats[0, v] = make_features_torch(1, H, W, C, dev, seed=v)[0].half()
     occ = torch.from_numpy(scene.occ[None].astype(np.int64)).to(dev)
     c2w = torch.from_numpy(scene.c2w).to(dev)
     intr = torch.from_numpy(scene.intr[None]).to(dev)
@@ -171,7 +179,7 @@ def main():
         ph, nt = int(count.sum().item()), int((count > 0).sum().item())
         hit_px += ph
         touched += nt
-        gather_bytes += ph * C * 4 + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
+        gather_bytes += ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
         c1 = voxproj_host.counters(ws, dev)
         for k in c1:
             cnt[k] = cnt.get(k, 0) + c1[k]
@@ -215,13 +223,14 @@ def main():
         gather_ms = prof["gather_ms"] / launches
         ach = (gather_bytes / len(calls)) / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
         # whole-path algorithmic bytes per step: feature rows + output RMW + counts + ID image w+r
-        algo_step = hit_px * C * 4 + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
+        algo_step = hit_px * C * esize + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
         res = {
             "metric": "Mvoxel-views/sec", "value": round(value, 3), "unit": "Mvoxel-views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if a.dtype == "f32" else "f32 accumulate, f16 feature maps",
             "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} fp32 feature maps, "
+            "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} {'fp32' if a.dtype == 'f32' else 'fp16'} feature maps, "
                                    f"room-shell scene seed 0, dmin 0.01 dmax 10 step 0.5*voxel",
                        "views_per_call": chunk, "resident_feature_maps": pool,
                        "parallelism": f"views r::{world} per GPU + one RCCL all-reduce of sum/count" if world > 1 else "single GPU"},
@@ -235,7 +244,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": (int(pmc_traffic(a.workload, chunk) * len(my_views) / len(calls))
-                                     if (not a.views and world == 1 and pmc_traffic(a.workload, chunk)) else None),
+                                     if (not a.views and world == 1 and a.dtype == "f32" and pmc_traffic(a.workload, chunk)) else None),
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline:

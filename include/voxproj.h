@@ -107,6 +107,23 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
 int vp_debug_spin(int mode, int blocks, int iters, const int32_t *table, int table_n, int32_t *sink, void *stream);
 
 /*
+ * Same as vp_project_features with the feature maps stored as IEEE binary16 [B,V,H,W,C] (C % 8 == 0).
+ * LSeg features are fp16 at rest (script/extract_lseg_features.py:97) and
+ * prepare_tensor_data.py:126 casts the resized maps back to fp16 before widening them, so every value the
+ * reference kernel reads is fp16-representable; this entry point reads half the bytes, widens exactly and
+ * accumulates in fp32 in the same order -- outputs are bit-identical to the fp32 path on the same data.
+ * (No reference counterpart: its wrapper insists on float32, W.cpp:46.)
+ */
+int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const float *vmi,
+                            const float *intr, const float *opts_host,
+                            int32_t *count, float *out, int32_t *views_hit,
+                            const float *grid_origin_host, float voxel_size,
+                            int B, int V, int H, int W, int C,
+                            int dimz, int dimy, int dimx, int64_t n_rows,
+                            void *workspace, size_t workspace_bytes,
+                            void *stream, int flags);
+
+/*
  * Pipelined mode: launches, on `stream`, the gather that the last VP_FLAG_PIPELINE call on this workspace
  * still owes (no-op otherwise).  Asynchronous; after it the outputs of every call made so far are ordered
  * on `stream` like any other work.

@@ -419,3 +419,57 @@ def test_pipelining_ab_arms_stay_exact(oracle_mod, monkeypatch, env):
     voxproj_host.workspace_status(ws, dev)
     assert np.array_equal(count_t.cpu().numpy(), count)
     assert out_t.cpu().numpy().tobytes() == out.tobytes()
+
+
+def test_fp16_feature_maps_give_the_fp32_bits(oracle_mod):
+    # the same data stored as binary16 must produce bit-identical sums/counts (exact widening,
+    # same summation order) -- normal wavefront path, C = 512 / 64 / 1000-rounded-to-8, and a pipelined sequence
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 5, 48, 32, seed=81, room=(5.0, 4.0, 2.4))
+    for C in (512, 64, 1000):
+        f16 = make_features_np(5, 32, 48, C, seed=81).astype(np.float16)
+        f32 = f16.astype(np.float32)
+        n_rows = s.n_vox + 1
+        count = np.zeros(n_rows, np.int32)
+        out = np.zeros((n_rows, C), np.float32)
+        oracle_mod.project_features(f32[None], s.occ[None].astype(np.int64), s.c2w.reshape(-1), s.intr[None], s.opts(),
+                                    s.grid_origin, s.voxel_size, count, out)
+        count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        out_t = torch.zeros(n_rows, C, device=dev)
+        ws = voxproj_host.Workspace()
+        occ_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+        c2w_t = torch.from_numpy(s.c2w).to(dev)
+        intr_t = torch.from_numpy(s.intr[None]).to(dev)
+        f_t = torch.from_numpy(f16[None]).to(dev)
+        vm = [c2w_t[a:b].reshape(-1).contiguous() for a, b in ((0, 2), (2, 5))]
+        for (a, b), v in zip(((0, 2), (2, 5)), vm):
+            voxproj_host.project_features_raw(f_t[:, a:b], occ_t, v, intr_t, [float(x) for x in s.opts()], count_t, out_t,
+                                              [float(x) for x in s.grid_origin], s.voxel_size, workspace=ws, sync=False,
+                                              pipeline=True)
+        voxproj_host.workspace_status(ws, dev)
+        assert np.array_equal(count_t.cpu().numpy(), count)
+        assert out_t.cpu().numpy().tobytes() == out.tobytes()
+
+
+def test_fp16_heavy_path(oracle_mod, monkeypatch):
+    import voxproj_host
+    monkeypatch.setenv("VOXPROJ_HEAVY_T", "6")
+    dev = torch.device(DEV)
+    s = make_scene(2000, 4, 48, 32, seed=82, room=(5.0, 4.0, 2.4))
+    C = 512
+    f16 = make_features_np(4, 32, 48, C, seed=82).astype(np.float16)
+    n_rows = s.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    r = oracle_mod.project_features(f16.astype(np.float32)[None], s.occ[None].astype(np.int64), s.c2w.reshape(-1), s.intr[None],
+                                    s.opts(), s.grid_origin, s.voxel_size, count, out, want_f64=True)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    ws = voxproj_host.project_features_raw(torch.from_numpy(f16[None]).to(dev), torch.from_numpy(s.occ[None].astype(np.int64)).to(dev),
+                                           torch.from_numpy(s.c2w).reshape(-1).to(dev), torch.from_numpy(s.intr[None]).to(dev),
+                                           [float(x) for x in s.opts()], count_t, out_t, [float(x) for x in s.grid_origin],
+                                           s.voxel_size, sync=True)
+    assert voxproj_host.counters(ws, dev)["n_heavy"] > 50
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    assert np.abs(out_t.cpu().numpy() - r["out64"]).max() <= 1e-4 * np.abs(r["out64"]).max()
