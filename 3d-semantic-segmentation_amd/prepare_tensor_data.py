@@ -53,13 +53,17 @@ def camera_for(entry, cams, downsample_factor=None):
     return intr, torch.from_numpy(c2w)
 
 
-def upsample_features(arr, size=None, device="cpu"):
-    """[C,h,w] array (any float dtype) -> float32 [H,W,C] tensor on ``device``."""
+def upsample_features(arr, size=None, device="cpu", keep_dtype=False):
+    """[C,h,w] array (any float dtype) -> [H,W,C] tensor on ``device``: float32 like the reference (PTD:152), or,
+    with ``keep_dtype``, in the file's own dtype (fp16 for LSeg features) -- the values are the same because
+    PTD:126 casts the resized map back to the file's dtype before widening it."""
     t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
     if size is not None and tuple(t.shape[1:]) != tuple(size):
         up = torch.nn.functional.interpolate(t.float()[None], size=tuple(size), mode="bilinear", align_corners=False)[0]
         t = up.to(t.dtype)                       # PTD:126  arr_upsampled.astype(arr.dtype)
-    return t.float().permute(1, 2, 0).contiguous()
+    if not (keep_dtype and t.dtype == torch.float16):
+        t = t.float()
+    return t.permute(1, 2, 0).contiguous()
 
 
 def main(argv=None):

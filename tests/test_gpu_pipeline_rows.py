@@ -133,3 +133,55 @@ def test_rgb_aggregator_matches_reference_dict_semantics():
     assert np.array_equal(r["voxel_coords"].numpy(), np.array(keys, np.int32))
     assert np.array_equal(r["hit_count"].numpy(), np.array([counts[k] for k in keys]))
     assert r["avg_color"].numpy().tobytes() == exp_avg.tobytes()
+
+
+def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
+    # aggregate_voxel_features_onthefly.main() on files laid out like the reference's inputs: voxel-grid PLY with header
+    # comments (AGG:65-92), camera JSON (PTD:56-72), fp16 .npy features [C,h,w] (script/extract_lseg_features.py:97).
+    # parity / fast / fast+fp16 modes must agree where they should.
+    import json
+
+    import aggregate_voxel_features_onthefly as agg
+    from synthetic_scene import make_scene
+    s = make_scene(1500, 5, 48, 32, seed=91, room=(5.0, 4.0, 2.4))
+    ply = tmp_path / f"scene_{s.n_vox}vox_grid.ply"
+    with open(ply, "w") as f:
+        f.write("ply\nformat ascii 1.0\n")
+        f.write(f"comment voxel_size {s.voxel_size!r}\ncomment grid_origin {float(s.grid_origin[0])!r} "
+                f"{float(s.grid_origin[1])!r} {float(s.grid_origin[2])!r}\n")
+        f.write(f"element vertex {s.n_vox}\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for q in s.points:
+            f.write(f"{float(q[0])!r} {float(q[1])!r} {float(q[2])!r}\n")
+    lseg = tmp_path / "features"
+    lseg.mkdir()
+    rng = np.random.default_rng(91)
+    images, C = {}, 16
+    for v in range(5):
+        name = f"DSC{v:05d}.JPG"
+        np.save(lseg / f"{name}.npy", rng.standard_normal((C, 16, 24)).astype(np.float16))      # half-res map, upsampled x2
+        c2w = s.c2w[v].astype(np.float64)
+        R = c2w[:3, :3].T                                   # PTD:165-172 inverts [R|t]
+        t = -R @ c2w[:3, 3]
+        images[str(v)] = {"name": name, "camera_id": 1, "R": R.tolist(), "tvec": t.tolist()}
+    # the entry point scales intrinsics by 0.5 (AGG:209, PTD:132-143): give it the double-resolution camera
+    cams = {"1": {"params": [float(x) * 2 for x in s.intr], "width": 96, "height": 64}}
+    cam_json = tmp_path / "camera_params.json"
+    cam_json.write_text(json.dumps({"images": images, "cameras": cams}))
+    outs = {}
+    for mode, extra in (("parity", []), ("fast", []), ("fast16", ["--half_features"])):
+        out_dir = tmp_path / mode
+        agg.main(["--mode", mode.replace("16", ""), "--lseg_dir", str(lseg), "--cam_params", str(cam_json), "--voxel_ply", str(ply),
+                  "--checkpoint_dir", str(out_dir), "--views_per_call", "2"] + extra)
+        f = out_dir / f"ALL_nonzero_voxel_features_5_vox{s.n_vox}.pt"
+        outs[mode] = torch.load(f)
+        assert set(outs[mode]) == {"xyz", "avg_feats", "voxel_coords"}
+        assert outs[mode]["avg_feats"].dtype == torch.float16 and outs[mode]["voxel_coords"].dtype == torch.int32
+    assert outs["parity"]["xyz"].shape[0] > 300
+    # fast and fast+fp16 are the same numbers; parity differs only by the reference's fp16 round trips (and row order)
+    assert torch.equal(outs["fast"]["avg_feats"], outs["fast16"]["avg_feats"])
+    assert torch.equal(outs["fast"]["voxel_coords"], outs["fast16"]["voxel_coords"])
+    key = lambda t: (t[:, 0].long() * 10**6 + t[:, 1].long() * 10**3 + t[:, 2].long())
+    pa, fa = torch.argsort(key(outs["parity"]["voxel_coords"])), torch.argsort(key(outs["fast"]["voxel_coords"]))
+    assert torch.equal(outs["parity"]["voxel_coords"][pa], outs["fast"]["voxel_coords"][fa])
+    a, b = outs["parity"]["avg_feats"][pa].float(), outs["fast"]["avg_feats"][fa].float()
+    assert (a - b).abs().max() <= 2e-2 * b.abs().max()
