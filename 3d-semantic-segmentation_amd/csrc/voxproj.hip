@@ -9,7 +9,7 @@
 //                          contraction, IEEE divide/sqrt, t += inc) -> first-hit voxel ID image and a
 //                          per-call integer hit histogram.  Pixel -> voxel assignment is bit-exact.
 //   phase 2  k_gather      one 64-lane wavefront per voxel: project the voxel's cube into every
-//                          view (view table staged in LDS), scan the small pixel box in the ID
+//                          view (lane = view, world->camera table from k_viewtab), scan the small pixel box in the ID
 //                          image for pixels that first-hit THIS voxel ("occlusion test"), and stream
 //                          their C-wide feature rows from HBM with 16-byte-per-lane coalesced loads,
 //                          accumulating in registers in (view, y, x) order; one non-atomic
@@ -559,7 +559,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                     bTu = bT2 - u;
                     bg = (T + p.inc) - T;
                     const float r = p.inc - bg;
-                    const bool fast = (eb >= (30u << 23)) & (eb < (0xfeu << 23)) & (p.inc < T) & (bg > 0.0f) & (fabsf(r) * 2.0f != u);
+                    const bool fast = (t > 0.0f) & (eb >= (30u << 23)) & (eb < (0xfeu << 23)) & (p.inc < T) & (bg > 0.0f) & (fabsf(r) * 2.0f != u);
                     brg = fast ? __builtin_amdgcn_rcpf(bg) * 0.999999f : 0.0f;   // under-estimate: m <= floor(A/g)
                 }
                 const int m = (int)fminf(fmaxf((bTu - t) * brg, 0.0f), (float)S);
