@@ -288,13 +288,13 @@ __global__ __launch_bounds__(256) void k_build_cells(const long long *__restrict
 __global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__restrict__ mask64,
                                                     const unsigned char *__restrict__ src,
                                                     unsigned char *__restrict__ dst,
-                                                    int nbz, int nby, int nbx, int B, int axis)
+                                                    int nbz, int nby, int nbx, long long nblk_padded, int B, int axis)
 {
-    const long long nblk = (long long)nbz * nby * nbx;
+    const long long nreal = (long long)nbz * nby * nbx;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblk * B) return;
-    const long long base = (i / nblk) * nblk;
-    const int blk = (int)(i - base);
+    if (i >= nreal * B) return;
+    const long long base = (i / nreal) * nblk_padded;     // per-batch tables are padded to 16 entries
+    const int blk = (int)(i % nreal);
     const int z = blk / (nby * nbx), r = blk - z * (nby * nbx), y = r / nbx, x = r - y * nbx;
     int best = 255;
     if (axis == 0) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__
         for (int q = 0; q < nbz; q++)
             best = min(best, max(abs(z - q), (int)src[base + ((long long)q * nby + y) * nbx + x]));
     }
-    dst[i] = (unsigned char)best;
+    dst[base + blk] = (unsigned char)best;
 }
 
 // Near field: for every cell of every block within one block of an occupied block, the Chebyshev distance in
@@ -1375,9 +1375,9 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, s0, (const long long *)occ, cell_of_id,
                            mask64, dimz, dimy, dimx, l.nby, l.nbx, l.nblk, B, (long long)n_rows);
         const int db = (int)((l.nblk * B + 255) / 256);
-        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, B, 0);
-        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, B, 1);
-        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, B, 2);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, l.nblk, B, 0);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, l.nblk, B, 1);
+        hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, l.nblk, B, 2);
         const long long near_waves = (long long)l.nbz * l.nby * l.nbx * B;
         hipLaunchKernelGGL(k_build_near, dim3((unsigned)((near_waves + 3) / 4)), dim3(256), 0, s0, mask64, (const unsigned char *)dist,
                            near2, dimz, dimy, dimx, l.nbz, l.nby, l.nbx, l.nblk, B);

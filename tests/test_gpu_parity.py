@@ -98,6 +98,22 @@ def test_batch_of_two_grids(oracle_mod):
     occ = np.stack([s.occ, s2.occ])
     intr = np.stack([s.intr, s.intr * np.float32(1.1)])
     _compare(oracle_mod, feats, occ, s.c2w, intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+    # three batches whose per-batch tables need padding (block count not a multiple of 16) and whose later
+    # batches are sparse: a distance field attached to the wrong batch offset would leap over isolated voxels
+    rng = np.random.default_rng(18)
+    sparse = []
+    for k in range(2):
+        o = np.zeros_like(s.occ)
+        idx = rng.choice(o.size, 60, replace=False)
+        o.reshape(-1)[idx] = rng.integers(1, s.n_vox, 60)
+        sparse.append(o)
+    occ3 = np.stack([s.occ, sparse[0], sparse[1]])
+    feats3 = make_features_np(6, 24, 40, 4, seed=19).reshape(3, 2, 24, 40, 4)
+    c2w3 = np.concatenate([s.c2w[:2], s.c2w[:2], s.c2w[2:4]])
+    intr3 = np.stack([s.intr, s.intr, s.intr])
+    r, _, _ = _compare(oracle_mod, feats3, occ3, c2w3, intr3, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1,
+                       expect_boxmiss=None)
+    assert (r["hits"][1:] > 0).sum() > 20
 
 
 def test_sparse_grid_with_misses(oracle_mod):
