@@ -247,7 +247,7 @@ def main():
                                      if (not a.views and world == 1 and a.dtype == "f32" and pmc_traffic(a.workload, chunk)) else None),
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)
             ncores = os.cpu_count() or 1
             res["cpu_baseline"] = cpu_baseline(scene, C, min(a.cpu_views, n_views), ncores)
         print(json.dumps(res), flush=True)
