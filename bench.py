@@ -124,7 +124,8 @@ def main():
     scene = make_scene(n_vox, n_views, W, H, seed=0)
     from view_sharding import reduce_partials, views_of_rank
     my_views = views_of_rank(n_views, rank, world)
-    chunk = max(1, min(a.chunk, len(my_views)))
+    # at least four calls per rank so that the pipelined mode can hide phase 1 of all but the first call
+    chunk = max(1, min(a.chunk, len(my_views), max(4, -(-len(my_views) // 4))))
     pool = max(chunk, (min(a.pool, len(my_views)) // chunk) * chunk)
 
     esize = 4 if a.dtype == "f32" else 2
