@@ -171,7 +171,7 @@ struct Params {
     long long n_rows;
 };
 
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_TILE = 3, ST_WORDS = 64 };
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_TILE = 3, ST_STUCK = 4, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
@@ -461,6 +461,12 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     const long long *occ_b = occ + (long long)b * cells;
     const float fw = (float)p.width, fh = (float)p.height;
     int id = 0;
+    // t += inc must make progress all the way to tEnd, or the loop (the reference's too, K.cu:47,81) never ends:
+    // ulp(t) <= ulp(tEnd), so it does iff adding inc changes tEnd.  Such a ray is reported, not marched.
+    if ((t < tEnd) && !(tEnd + p.inc > tEnd)) {
+        atomicOr(&status[ST_STUCK], 1);
+        t = tEnd;
+    }
     if constexpr (!ACCEL) {
         while (t < tEnd) {
             const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
@@ -596,6 +602,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                 const int n = __popcll(m);
                 const int old = atomicAdd(&cnt_call[cur], n);
                 if (old <= heavy_t && old + n > heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = cur;
+
             }
             todo &= ~m;
         }
@@ -1594,6 +1601,9 @@ int vp_workspace_status(void *workspace, void *stream_)
     if (rc != VP_OK) return rc;
     PipeState *ps = pipe_state(workspace, false);
     const bool second = ps && (ps->used[1] || ps->calls > 1);
+    if (st[ST_STUCK] || (second && st[ST_WORDS + ST_STUCK]))
+        return fail(VP_EINVAL, "rayIncrement is too small to advance a float32 ray parameter near depthMax: the reference "
+                               "loop would never terminate (those rays were skipped, outputs are incomplete)");
     if (st[ST_BADID] || (second && st[ST_WORDS + ST_BADID]))
         return fail(VP_EBADID, "a ray hit an occupancy ID outside [1, n_rows): outputs are too small for the grid's IDs");
     return VP_OK;

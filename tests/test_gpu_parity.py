@@ -499,3 +499,14 @@ def test_negative_depth_min_marches_from_behind_the_camera(oracle_mod):
     feats = make_features_np(2, 24, 40, 8, seed=57)[None]
     opts = np.array([40, 24, -1.5, 6.0, 0.5 * s.voxel_size], np.float32)
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, opts, s.grid_origin, s.voxel_size, s.n_vox + 1, expect_boxmiss=None)
+
+
+def test_increment_too_small_to_advance_raises_instead_of_hanging(oracle_mod):
+    # inc below half an ulp of t: the reference's while-loop never terminates (K.cu:47,81); here it is an error
+    s = make_scene(2000, 1, 16, 8, seed=58, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(1, 8, 16, 4, seed=58)[None]
+    count_t = torch.zeros(s.n_vox + 1, dtype=torch.int32, device=DEV)
+    out_t = torch.zeros(s.n_vox + 1, 4, device=DEV)
+    opts = np.array([16, 8, 0.01, 10.0, 1e-8], np.float32)
+    with pytest.raises(RuntimeError, match="never terminate"):
+        _gpu_call(feats, s.occ[None], s.c2w, s.intr, opts, s.grid_origin, s.voxel_size, count_t, out_t)
