@@ -1206,6 +1206,67 @@ __global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ 
     if (first_view) first_view[id] = fv;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage-5 front end: nearest voxel of every Gaussian centre.  The reference builds an sklearn
+// KDTree over the voxel positions and queries k = 1 (voxel_to_gaussian/voxeltoGaussian_logits.py:87-105, same
+// code at voxeltoGaussian.py:84-93); distances there are float64 sums of squared float32 differences.  Here the
+// voxel positions are bucketed on a uniform grid (sorted by cell on the host side) and each lane searches
+// Chebyshev shells of cells around its query until the best squared distance (same float64 arithmetic) is
+// no larger than what any unexplored shell could offer: a point in a cell k shells away is at least (k-1)*h
+// away.  Exact; ties go to the lowest voxel index.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nearest_voxel(const float *__restrict__ pts, const int *__restrict__ perm,
+                                                       const int *__restrict__ cell_start, double gx, double gy,
+                                                       double gz, double h, int nx, int ny, int nz,
+                                                       const float *__restrict__ q, long long M, long long *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double qx = (double)q[i * 3 + 0], qy = (double)q[i * 3 + 1], qz = (double)q[i * 3 + 2];
+    // query cell in (possibly out-of-range) grid coordinates
+    const double fx = floor((qx - gx) / h), fy = floor((qy - gy) / h), fz = floor((qz - gz) / h);
+    const double lim = 1.0e9;
+    const long long cx = (long long)fmin(fmax(fx, -lim), lim), cy = (long long)fmin(fmax(fy, -lim), lim),
+                    cz = (long long)fmin(fmax(fz, -lim), lim);
+    // first shell that can touch the grid
+    long long r0 = 0;
+    r0 = max(r0, max(-cx, cx - (nx - 1)));
+    r0 = max(r0, max(-cy, cy - (ny - 1)));
+    r0 = max(r0, max(-cz, cz - (nz - 1)));
+    const long long rmax = r0 + (long long)max(nx, max(ny, nz)) + 1;
+    double best = INFINITY;
+    long long best_idx = -1;
+    for (long long r = r0; r <= rmax; r++) {
+        const long long z0 = max(cz - r, 0ll), z1 = min(cz + r, (long long)nz - 1);
+        const long long y0 = max(cy - r, 0ll), y1 = min(cy + r, (long long)ny - 1);
+        const long long x0 = max(cx - r, 0ll), x1 = min(cx + r, (long long)nx - 1);
+        for (long long z = z0; z <= z1; z++)
+            for (long long y = y0; y <= y1; y++) {
+                const bool face = (llabs(z - cz) == r) || (llabs(y - cy) == r);
+                for (long long x = x0; x <= x1; x++) {
+                    if (!face && llabs(x - cx) != r) {          // interior of the shell: jump to the far side
+                        if (x < cx + r && cx + r <= x1) x = cx + r - 1;
+                        else break;
+                        continue;
+                    }
+                    const long long c = (z * ny + y) * nx + x;
+                    for (int k = cell_start[c]; k < cell_start[c + 1]; k++) {
+                        const double dx = qx - (double)pts[(long long)k * 3 + 0];
+                        const double dy = qy - (double)pts[(long long)k * 3 + 1];
+                        const double dz = qz - (double)pts[(long long)k * 3 + 2];
+                        const double d2 = dx * dx + dy * dy + dz * dz;
+                        const long long idx = perm[k];
+                        if (d2 < best || (d2 == best && idx < best_idx)) { best = d2; best_idx = idx; }
+                    }
+                }
+            }
+        // everything in shells > r is at least r*h away
+        const double bound = (double)r * h;
+        if (best_idx >= 0 && best <= bound * bound) break;
+    }
+    out[i] = best_idx;
+}
+
 // diagnostic co-runner (tools/dbg_corun.py): mode 0 = pure VALU, 1 = dependent scattered L2 loads,
 // 2 = returning int atomics on a small table
 __global__ __launch_bounds__(256) void k_debug_spin(int mode, int iters, const int *table, int table_n, int *sink)
@@ -1575,6 +1636,20 @@ static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WO
     }
     VP_HIP(hipMemcpyAsync(st, workspace, 2 * align256(ST_WORDS * sizeof(int)), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
+    return VP_OK;
+}
+
+int vp_nearest_voxel(const float *pts_sorted, const int32_t *perm, const int32_t *cell_start, const double *grid_origin3,
+                     double cell_size, int nx, int ny, int nz, const float *queries, int64_t M, int64_t *out,
+                     void *stream_)
+{
+    if (!pts_sorted || !perm || !cell_start || !grid_origin3 || !queries || !out) return fail(VP_EINVAL, "null pointer argument");
+    if (!(cell_size > 0.0) || nx <= 0 || ny <= 0 || nz <= 0 || M < 0) return fail(VP_EINVAL, "bad grid or query count");
+    if (M == 0) return VP_OK;
+    hipLaunchKernelGGL(k_nearest_voxel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, pts_sorted,
+                       (const int *)perm, (const int *)cell_start, grid_origin3[0], grid_origin3[1], grid_origin3[2],
+                       cell_size, nx, ny, nz, queries, (long long)M, (long long *)out);
+    VP_HIP(hipGetLastError());
     return VP_OK;
 }
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
     "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors", "vp_workspace_flush",
-    "vp_debug_spin", "vp_project_features_f16",
+    "vp_debug_spin", "vp_project_features_f16", "vp_nearest_voxel",
 ]
 
 
@@ -64,6 +64,9 @@ def lib():
                 ctypes.c_float] + [ctypes.c_int] * 8 + [ctypes.c_int64, vp, ctypes.c_size_t, vp, ctypes.c_int]
             L.vp_project_features_f16.restype = ctypes.c_int
             L.vp_project_features_f16.argtypes = L.vp_project_features.argtypes
+            L.vp_nearest_voxel.restype = ctypes.c_int
+            L.vp_nearest_voxel.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, vp, ctypes.c_int64, vp, vp]
             L.vp_workspace_status.restype = ctypes.c_int
             L.vp_workspace_status.argtypes = [vp, vp]
             L.vp_workspace_flush.restype = ctypes.c_int

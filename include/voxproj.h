@@ -101,6 +101,21 @@ int vp_project_features(const float *feats, const int64_t *occ, const float *vmi
                         void *stream, int flags);
 
 /*
+ * Stage-5 front end: index of the nearest voxel for each of M Gaussian centres -- replaces
+ * map_gaussians_to_voxels (voxel_to_gaussian/voxeltoGaussian_logits.py:87-105; identical code at
+ * voxel_to_gaussian/voxeltoGaussian.py:84-93: sklearn KDTree(leaf_size=16).query(k=1) in float64).
+ *   pts_sorted  f32 [N,3] voxel positions sorted by grid cell (device)
+ *   perm        i32 [N]   original index of each sorted position
+ *   cell_start  i32 [nx*ny*nz + 1] first sorted position of each cell ((z*ny + y)*nx + x order)
+ *   grid_origin3 f64 [3] HOST, cell_size, nx, ny, nz: the bucketing grid
+ *   queries     f32 [M,3] device;  out i64 [M] device: nearest original index (lowest index on exact ties)
+ * Asynchronous on `stream`.
+ */
+int vp_nearest_voxel(const float *pts_sorted, const int32_t *perm, const int32_t *cell_start,
+                     const double *grid_origin3, double cell_size, int nx, int ny, int nz,
+                     const float *queries, int64_t M, int64_t *out, void *stream);
+
+/*
  * Diagnostic co-runner used by tools/dbg_corun.py to study what slows the gather when another kernel shares
  * the GPU (mode 0 pure VALU, 1 dependent scattered L2 loads, 2 returning integer atomics).  Not a product path.
  */

@@ -185,3 +185,23 @@ def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
     assert torch.equal(outs["parity"]["voxel_coords"][pa], outs["fast"]["voxel_coords"][fa])
     a, b = outs["parity"]["avg_feats"][pa].float(), outs["fast"]["avg_feats"][fa].float()
     assert (a - b).abs().max() <= 2e-2 * b.abs().max()
+
+
+def test_nearest_voxel_map_matches_reference_kdtree():
+    # golden = the reference's own map_gaussians_to_voxels (sklearn KDTree, k=1) run in the build container
+    from make_stage5_golden import inputs
+    from voxel_to_gaussian_map import map_gaussians_to_voxels
+    g = np.load(os.path.join(HERE, "golden", "nearest_voxel_golden.npz"))
+    vox, mu = inputs()
+    assert vox.astype(np.float64).sum() == float(g["vox_checksum"]) and mu.astype(np.float64).sum() == float(g["mu_checksum"])
+    got = map_gaussians_to_voxels(torch.from_numpy(vox), torch.from_numpy(mu), device=DEV)
+    assert got.dtype == torch.int64 and got.device.type == "cpu" and got.shape == (len(mu),)
+    got = got.numpy()
+    ref = g["idx"]
+    diff = np.nonzero(got != ref)[0]
+    # where the index differs the two voxels must be exactly equidistant (sklearn's tie choice is unspecified)
+    d_got = ((mu[diff].astype(np.float64) - vox[got[diff]].astype(np.float64)) ** 2).sum(1)
+    d_ref = ((mu[diff].astype(np.float64) - vox[ref[diff]].astype(np.float64)) ** 2).sum(1)
+    assert np.array_equal(d_got, d_ref)
+    assert len(diff) < 0.01 * len(ref)
+    assert np.array_equal(got[-300:], np.arange(300))            # centres sitting exactly on voxels map to them
