@@ -39,7 +39,7 @@ def build(force=False):
     hdr = os.path.join(os.path.dirname(_HERE), "include", "voxproj.h")
     newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
 

@@ -24,7 +24,7 @@ def build(force=False):
     """Compile oracle/_build/liboracle.so with gcc (see oracle/Makefile)."""
     src = os.path.join(_HERE, "projector_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
 
