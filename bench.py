@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-overlap-reduce", action="store_true",
+                    help="multi-GPU: wait for each pass's all-reduce before starting the next pass (default: the "
+                         "all-reduce of pass k runs on RCCL's stream while pass k+1 is projected into a second buffer)")
     return ap.parse_args()
 
 
@@ -156,20 +159,44 @@ def main():
 
     pipeline = not a.no_pipeline
 
-    def one_call(ci, sync=False):
+    def one_call(ci, sync=False, o=None, c=None):
         slot, vs = calls[ci]
-        voxproj_host.project_features_raw(feats[:, slot:slot + len(vs)], occ, vmis[ci], intr, opts, count, out,
+        voxproj_host.project_features_raw(feats[:, slot:slot + len(vs)], occ, vmis[ci], intr, opts,
+                                          count if c is None else c, out if o is None else o,
                                           origin, scene.voxel_size, workspace=ws, sync=sync,
                                           reuse_accel=(ci > 0 or None), pipeline=(pipeline and not sync))
 
+    # multi-GPU: two output buffers, so that the all-reduce of pass k (RCCL's own stream, over xGMI) overlaps the
+    # projection of pass k+1; every reduction is waited for before its buffer is reused and before the timed
+    # region ends
+    bufs = [(out, count)]
+    if dist is not None and not a.no_overlap_reduce:
+        bufs.append((torch.zeros_like(out), torch.zeros_like(count)))
+    inflight = [None] * len(bufs)
+    state = {"k": 0}
+
+    def drain(i=None):
+        for j in (range(len(bufs)) if i is None else [i]):
+            if inflight[j] is not None:
+                for w in inflight[j]:
+                    w.wait()
+                inflight[j] = None
+
     def step():
-        count.zero_()
-        out.zero_()
+        i = state["k"] % len(bufs)
+        state["k"] += 1
+        o, c = bufs[i]
+        drain(i)
+        c.zero_()
+        o.zero_()
         for ci in range(len(calls)):
-            one_call(ci)
+            one_call(ci, o=o, c=c)
         voxproj_host.workspace_flush(ws, dev)      # pipelined mode: the last call's gather is part of the pass
         if dist is not None:
-            reduce_partials(dist, [out, count])
+            if a.no_overlap_reduce:
+                reduce_partials(dist, [o, c])
+            else:
+                inflight[i] = [dist.all_reduce(o, async_op=True), dist.all_reduce(c, async_op=True)]
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px = 0, 0, 0, {}, 0
@@ -196,11 +223,13 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    drain()
     barrier()
     voxproj_host.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     voxproj_host.workspace_status(ws, dev)
@@ -217,6 +246,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    algo_local = hit_px * C * esize + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
+    if dist is not None:
+        t = torch.tensor([algo_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        algo_local = float(t.item())
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = n_vox * n_views / (dt / a.steps) / 1e6
@@ -224,7 +258,7 @@ def main():
         gather_ms = prof["gather_ms"] / launches
         ach = (gather_bytes / len(calls)) / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
         # whole-path algorithmic bytes per step: feature rows + output RMW + counts + ID image w+r
-        algo_step = hit_px * C * esize + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
+        algo_step = algo_local      # summed over ranks
         res = {
             "metric": "Mvoxel-views/sec", "value": round(value, 3), "unit": "Mvoxel-views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
@@ -234,7 +268,9 @@ def main():
             "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} {'fp32' if a.dtype == 'f32' else 'fp16'} feature maps, "
                                    f"room-shell scene seed 0, dmin 0.01 dmax 10 step 0.5*voxel",
                        "views_per_call": chunk, "resident_feature_maps": pool,
-                       "parallelism": f"views r::{world} per GPU + one RCCL all-reduce of sum/count" if world > 1 else "single GPU"},
+                       "parallelism": (f"views r::{world} per GPU + one RCCL all-reduce of sum/count per pass"
+                                       + ("" if a.no_overlap_reduce else ", overlapped with the next pass (two output buffers)"))
+                       if world > 1 else "single GPU"},
             "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
             "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
                                   "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
