@@ -26,6 +26,7 @@ EXPORTS = [
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
     "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors", "vp_workspace_flush",
     "vp_debug_spin", "vp_project_features_f16", "vp_nearest_voxel",
+    "vp_stream_read",
 ]
 
 
@@ -274,3 +275,22 @@ def project_colors_raw(occ_zyx, c2w, intr, grid_origin3, voxel_size, images, col
             images.data_ptr(), int(images.shape[1]), int(images.shape[2]), color_sum.data_ptr(), hit_count.data_ptr(),
             first_view.data_ptr() if first_view is not None else None, n_rows, int(view_base), status.data_ptr(),
             stream))
+
+
+def stream_read_gbs(buf, repeats=3):
+    """Measured streaming-read rate (GB/s) of this GPU over the float32 CUDA tensor ``buf`` (non-temporal loads)."""
+    import torch
+    L = lib()
+    L.vp_stream_read.restype = ctypes.c_int
+    L.vp_stream_read.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(4, dtype=torch.float32, device=buf.device)
+    n = (buf.numel() * buf.element_size() // 16) * 4
+    stream = torch.cuda.current_stream(buf.device).cuda_stream
+    check(L.vp_stream_read(buf.data_ptr(), n, sink.data_ptr(), stream))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(repeats):
+        check(L.vp_stream_read(buf.data_ptr(), n, sink.data_ptr(), stream))
+    e1.record()
+    e1.synchronize()
+    return n * 4 * repeats / (e0.elapsed_time(e1) * 1e-3) / 1e9

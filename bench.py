@@ -251,6 +251,7 @@ def main():
         t = torch.tensor([algo_local], dtype=torch.float64, device=dev)
         dist.all_reduce(t)
         algo_local = float(t.item())
+    stream_gbs = voxproj_host.stream_read_gbs(feats) if rank == 0 else 0.0   # on-box streaming-read ceiling
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = n_vox * n_views / (dt / a.steps) / 1e6
@@ -280,6 +281,8 @@ def main():
             "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "measured_stream_read_gbs": round(stream_gbs, 1),
+                         "frac_of_measured_stream_read": round(ach / stream_gbs, 4) if stream_gbs > 0 else None,
                          "traffic": (int(pmc_traffic(a.workload, chunk) * len(my_views) / len(calls))
                                      if (not a.views and world == 1 and a.dtype == "f32" and pmc_traffic(a.workload, chunk)) else None),
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},

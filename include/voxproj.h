@@ -116,6 +116,13 @@ int vp_nearest_voxel(const float *pts_sorted, const int32_t *perm, const int32_t
                      const float *queries, int64_t M, int64_t *out, void *stream);
 
 /*
+ * Measurement aid: streams n_floats (a multiple of 4, 16-byte aligned) from `src` with non-temporal 16-byte
+ * loads and discards them -- bench.py times it to quote the gather against the box's own streaming-read
+ * ceiling as well as the nominal HBM peak.  No reference counterpart.
+ */
+int vp_stream_read(const float *src, int64_t n_floats, float *sink, void *stream);
+
+/*
  * Diagnostic co-runner used by tools/dbg_corun.py to study what slows the gather when another kernel shares
  * the GPU (mode 0 pure VALU, 1 dependent scattered L2 loads, 2 returning integer atomics).  Not a product path.
  */
