@@ -592,19 +592,21 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     // slow a concurrently running gather 3-4x; this issues ~8x fewer of them).  The add that lifts a voxel's
     // per-call count above heavy_t enlists it for the workgroup path.
     {
+        // every lane leads at most one group (the group of its own ID), so the group sizes are collected first and
+        // ALL groups are added by one wave-level atomic instruction: one memory round trip instead of one per group
         const int lane_ = threadIdx.x & 63;
+        int my_n = 0;
         unsigned long long todo = __ballot(id != 0);
         while (todo) {
             const int l = __builtin_ctzll(todo);
             const int cur = __builtin_amdgcn_readlane(id, l);
             const unsigned long long m = __ballot(id == cur);
-            if (lane_ == l) {
-                const int n = __popcll(m);
-                const int old = atomicAdd(&cnt_call[cur], n);
-                if (old <= heavy_t && old + n > heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = cur;
-
-            }
+            if (lane_ == l) my_n = __popcll(m);
             todo &= ~m;
+        }
+        if (my_n > 0) {
+            const int old = atomicAdd(&cnt_call[id], my_n);
+            if (old <= heavy_t && old + my_n > heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = id;
         }
     }
 }
@@ -1527,7 +1529,11 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
             if (lds_req > 160 * 1024) lds_req = 160 * 1024;
             hipLaunchKernelGGL((k_first_hit<2, 4, 4>), dim3((W + 31) / 32, (H + 31) / 32, B * V), dim3(1024), lds_req, s1, FH_ARGS);
         } else {
-            size_t lds_req = 0;   // a dynamic-LDS request caps this kernel's workgroups per CU (pipelined mode)
+            // Occupancy shaping for the pipelined mode: a 41-KiB dynamic-LDS reservation (the kernel does not touch
+            // it) admits at most 3 march workgroups = 12 wavefronts per CU.  Spread that thin the march still
+            // finishes under the gather of the previous call (40 ms vs 50 ms per R2 pass) and costs the gather
+            // ~1 % instead of ~8 % (measured: 54.2 -> 52.0 ms per pass); alone it runs unrestricted.
+            size_t lds_req = pipe ? 41 * 1024 : 0;
             if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
             hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), lds_req, s1, FH_ARGS);
         }
