@@ -116,11 +116,6 @@ struct PipeState {
     bool used[2] = {false, false};
     long long calls = 0;
     int last_q = 0;
-    // fused mode: the call whose phase 1 has been launched and whose gather is still owed
-    bool pending = false;
-    struct GatherArgs *pend_g = nullptr;
-    struct Params *pend_p = nullptr;
-    int pend_vec_ok = 0;
 };
 // offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
 std::vector<std::pair<const void *, size_t>> g_last_hit;
@@ -171,7 +166,7 @@ struct Params {
     long long n_rows;
 };
 
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_TILE = 3, ST_STUCK = 4, ST_WORDS = 64 };
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
@@ -397,8 +392,7 @@ __global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
 //     for samples that found an occupied cell (it gates nothing else).
 // Every evaluated sample uses the reference's exact fp32 operations, so the first-hit ID is identical.
 // ------------------------------------------------------------------------------------------------
-// MODE 0: reference loop; 1: leaping march, distance field read through L2; 2: leaping march with the
-// block distance field staged in LDS by the workgroup (32x32-pixel workgroups, two per CU).
+// MODE 0: the reference loop (A/B arm, VP_FLAG_EXACT_MARCH); MODE 1: the leaping march.
 struct FirstHitArgs {
     const long long *occ;
     const float *vmi;
@@ -415,8 +409,7 @@ struct FirstHitArgs {
 };
 
 template <int MODE>
-__device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Params &p, int x, int y, int bv,
-                                               unsigned char *lds_dist)
+__device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Params &p, int x, int y, int bv)
 {
     constexpr bool ACCEL = MODE != 0;
     const long long *__restrict__ occ = fa.occ;
@@ -523,7 +516,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                     cur_blk = blk;
                     // both table reads go out together (the bit planes are only meaningful when cur_d <= 1)
                     const ulonglong2 n2 = near_b[blk];
-                    cur_d = (MODE == 2) ? lds_dist[blk] : dist_b[blk];
+                    cur_d = dist_b[blk];
                     cur_lo = n2.x; cur_hi = n2.y;
                 }
                 const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
@@ -547,7 +540,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                 const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
                 const int kx = min(max(jx, 0), p.dimx - 1), ky = min(max(jy, 0), p.dimy - 1), kz = min(max(jz, 0), p.dimz - 1);
                 const int cb_ = ((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2);
-                const int dd = (MODE == 2) ? lds_dist[cb_] : dist_b[cb_];
+                const int dd = dist_b[cb_];
                 const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
                 D = max(dbox, din - dbox);
             }
@@ -611,42 +604,13 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     }
 }
 
-template <int MODE, int WX, int WY>
-__global__ __launch_bounds__(64 * WX * WY) void k_first_hit(FirstHitArgs fa, Params p)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_first_hit(FirstHitArgs fa, Params p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dist[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x * (8 * WX) + (wave % WX) * 8 + (lane & 7);
-    const int y = blockIdx.y * (8 * WY) + (wave / WX) * 8 + (lane >> 3);
-    const int bv = blockIdx.z;
-    if constexpr (MODE == 2) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(fa.dist + (long long)(bv / p.V) * fa.nblk);   // 256-byte aligned per batch
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_dist);
-        const int n16 = (int)((fa.nblk + 15) >> 4);
-        for (int i = threadIdx.x; i < n16; i += 64 * WX * WY) dst[i] = src[i];
-        __syncthreads();
-    }
-    first_hit_body<MODE>(fa, p, x, y, bv, lds_dist);
-}
-
-// Persistent form for the pipelined mode: a fixed number of workgroups whose wavefronts pull 8x8-pixel tiles
-// from an atomic counter until none are left (the counter only grows, so every wave reaches the exit).  Run
-// beside the gather it keeps a fixed, small number of march waves on every CU instead of fighting the
-// gather's short-lived workgroups for placement.
-__global__ __launch_bounds__(256) void k_first_hit_workers(FirstHitArgs fa, Params p, int tiles_x, int tiles_y,
-                                                           int n_tiles, int *tile_counter)
-{
-    const int lane = threadIdx.x & 63;
-    for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = atomicAdd(tile_counter, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= n_tiles) return;
-        const int bv = tile / (tiles_x * tiles_y);
-        const int r = tile - bv * (tiles_x * tiles_y);
-        const int ty = r / tiles_x, tx = r - ty * tiles_x;
-        first_hit_body<1>(fa, p, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), bv, nullptr);
-    }
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    first_hit_body<MODE>(fa, p, x, y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -733,7 +697,8 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
 #pragma unroll
                             for (int k = 0; k < K; k++) {
                                 const int ch = (k * 64 + lane) * 4;
-#ifndef VP_NO_NT   // feature rows are read exactly once: non-temporal loads keep them out of L2/MALL (+12 % measured)
+                                // feature rows are read exactly once: non-temporal loads keep them out of L2/MALL
+                                // (+12 % gather bandwidth measured against plain loads)
                                 typedef float v4f_ __attribute__((ext_vector_type(4)));
                                 if (cb + ch < C) {
                                     const v4f_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(fv + off[j] + ch));
@@ -741,11 +706,6 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
                                 } else {
                                     r[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
                                 }
-#else
-                                r[j][k] = (cb + ch < C)
-                                              ? *reinterpret_cast<const float4 *>(fv + off[j] + ch)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
                             }
                         }
 #pragma unroll
@@ -1125,38 +1085,6 @@ __global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p
     }
 }
 
-// Fused pipeline step: ONE launch holds the gather of call j and the ray-march of call j+1.  The first
-// `n_workers` workgroups are persistent march workers: each wavefront pulls 8x8-pixel tiles from an atomic
-// counter until none are left (every wave reaches the exit: the counter only grows).  They are dispatched
-// first, so each CU keeps a fixed small number of issue-bound march waves while the HBM-bound gather
-// workgroups behind them in the grid fill the remaining slots.  (Two concurrent streams, and a plain
-// 1:1 interleave of march and gather workgroups, were both measured to starve the gather of wave slots.)
-template <int K, int VEC, int U>
-__global__ __launch_bounds__(256) void k_fused(GatherArgs g, Params pg, FirstHitArgs fa, Params pf, int n_workers,
-                                               int tiles_x, int tiles_y, int n_tiles, int *tile_counter)
-{
-    const int lane = threadIdx.x & 63;
-    if ((int)blockIdx.x < n_workers) {
-        for (;;) {
-            int tile = 0;
-            if (lane == 0) tile = atomicAdd(tile_counter, 1);
-            tile = __builtin_amdgcn_readfirstlane(tile);
-            if (tile >= n_tiles) return;
-            const int bv = tile / (tiles_x * tiles_y);
-            const int r = tile - bv * (tiles_x * tiles_y);
-            const int ty = r / tiles_x, tx = r - ty * tiles_x;
-            first_hit_body<1>(fa, pf, tx * 8 + (lane & 7), ty * 8 + (lane >> 3), bv, nullptr);
-        }
-    }
-    const long long gi = (long long)blockIdx.x - n_workers;
-    const long long idl = gi * 4 + (threadIdx.x >> 6) + 1;
-    if (idl >= pg.n_rows) return;
-    const int id = (int)idl;
-    const int expected = g.cnt_call[id];
-    if (expected == 0 || expected > g.heavy_t) return;
-    gather_voxel_wave<K, VEC, U>(g, pg, id, expected, lane);
-}
-
 // ------------------------------------------------------------------------------------------------
 // RGB path (BASELINE config 5): the reference's debug_project_colors.py:54-81 is a per-voxel Python loop --
 // voxel-driven, nearest pixel, NO occlusion test, numpy float64 arithmetic.  One lane per grid cell; an
@@ -1269,29 +1197,6 @@ __global__ __launch_bounds__(256) void k_nearest_voxel(const float *__restrict__
     out[i] = best_idx;
 }
 
-// diagnostic co-runner (tools/dbg_corun.py): mode 0 = pure VALU, 1 = dependent scattered L2 loads,
-// 2 = returning int atomics on a small table
-__global__ __launch_bounds__(256) void k_debug_spin(int mode, int iters, const int *table, int table_n, int *sink)
-{
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    float a = (float)tid * 1e-3f, b = 1.0001f;
-    int idx = tid % table_n;
-    int acc = 0;
-    for (int i = 0; i < iters; i++) {
-        if (mode == 0) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) a = a * b + 0.5f;
-        } else if (mode == 1) {
-            idx = (table[idx] + tid + i * 97) % table_n;
-            acc += idx;
-        } else {
-            acc += atomicAdd(&sink[64 + (idx % 4096)], 1);
-            idx = (idx * 31 + 7) % table_n;
-        }
-    }
-    if (a == 12345.678f || acc == 0x7fffffff) sink[0] = 1;
-}
-
 // measurement aid (bench.py): plain streaming read of a buffer with 16-byte non-temporal loads, the on-box
 // ceiling the gather's achieved bandwidth is quoted against next to the nominal HBM peak
 __global__ __launch_bounds__(256) void k_stream_read(const float *__restrict__ src, long long n_vec4, float *sink)
@@ -1320,51 +1225,16 @@ __global__ __launch_bounds__(256) void k_stream_read(const float *__restrict__ s
 // ------------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------------
-#ifndef VP_U
-#define VP_U 4
-#endif
 // VEC_OK: 0 = scalar fp32 path, 1 = 16-byte vector fp32 path, 2 = fp16 feature maps
 #define VP_DISPATCH_KVU(KERNEL, VEC_OK, C, ...)                                   \
     do {                                                                          \
-        if ((VEC_OK) == 2) hipLaunchKernelGGL((KERNEL<1, 8, VP_U>), __VA_ARGS__); \
-        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, VP_U>), __VA_ARGS__); \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((KERNEL<1, 8, 4>), __VA_ARGS__);    \
+        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), __VA_ARGS__); \
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
 
 constexpr int HEAVY_BLOCKS = 128;
-
-// heavy-voxel kernel + plain gather of one call on `stream`
-int launch_gather(const GatherArgs &g, const Params &p, int vec_ok, size_t glds, hipStream_t stream)
-{
-    const int blocks_n = (int)((p.n_rows - 1 + 3) / 4);
-    {
-        ProfSpan sp; sp.begin(3, stream);
-        VP_DISPATCH_KVU(k_gather_heavy, vec_ok, p.C, dim3(HEAVY_BLOCKS), dim3(GW * 64), 0, stream, g, p);
-        sp.end();
-    }
-    if (blocks_n > 0) {
-        ProfSpan sp; sp.begin(2, stream);
-        VP_DISPATCH_KVU(k_gather, vec_ok, p.C, dim3(blocks_n), dim3(256), glds, stream, g, p);
-        sp.end();
-    }
-    VP_HIP(hipGetLastError());
-    return VP_OK;
-}
-
-// fused mode: launch the gather that is still owed for the last pipelined call on this workspace
-int flush_pending(PipeState *ps, hipStream_t stream)
-{
-    if (!ps || !ps->pending) return VP_OK;
-    ps->pending = false;
-    return launch_gather(*ps->pend_g, *ps->pend_p, ps->pend_vec_ok, 0, stream);
-}
-
-bool fused_mode()
-{
-    const char *e = getenv("VOXPROJ_PIPE");
-    return e && strcmp(e, "fused") == 0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
@@ -1421,19 +1291,13 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const bool pipe = (flags & VP_FLAG_PIPELINE) != 0;
     PipeState *ps = pipe_state(workspace, pipe);
     if (pipe && !ps) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
-    const bool fused = pipe && fused_mode();
     int q = 0;
     hipStream_t s1 = s0;
-    if (fused) {
-        q = (int)(ps->calls & 1);
-    } else if (pipe) {
-        { int rc_ = flush_pending(ps, s0); if (rc_ != VP_OK) return rc_; }
+    if (pipe) {
         q = (int)(ps->calls & 1);
         s1 = ps->side;
-    } else if (ps && ps->pending) {
-        { int rc_ = flush_pending(ps, s0); if (rc_ != VP_OK) return rc_; }
     } else if (ps && (ps->used[0] || ps->used[1])) {
-        // a plain call after pipelined ones on this workspace: drain the side stream first
+        // a plain call after pipelined ones on this workspace: drain the side streams first
         VP_HIP(hipStreamSynchronize(ps->side));
         VP_HIP(hipStreamSynchronize(ps->side2));
         ps->used[0] = ps->used[1] = false;
@@ -1452,10 +1316,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
 
     if (!(flags & VP_FLAG_REUSE_ACCEL)) {
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
-        if (fused) {
-            int rc_ = flush_pending(ps, s0);
-            if (rc_ != VP_OK) return rc_;
-        } else if (pipe) {
+        if (pipe) {
             VP_HIP(hipStreamSynchronize(ps->side));
             VP_HIP(hipStreamSynchronize(ps->side2));
             VP_HIP(hipStreamSynchronize(s0));
@@ -1467,7 +1328,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         const int blocks = (int)((cells * B + 255) / 256 > 16384 ? 16384 : (cells * B + 255) / 256);
         hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, s0, (const long long *)occ, cell_of_id,
                            mask64, dimz, dimy, dimx, l.nby, l.nbx, l.nblk, B, (long long)n_rows);
-        const int db = (int)((l.nblk * B + 255) / 256);
+        const int db = (int)(((long long)l.nbz * l.nby * l.nbx * B + 255) / 256);
         hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)nullptr, dist, l.nbz, l.nby, l.nbx, l.nblk, B, 0);
         hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist, dist_tmp, l.nbz, l.nby, l.nbx, l.nblk, B, 1);
         hipLaunchKernelGGL(k_block_dist, dim3(db), dim3(256), 0, s0, mask64, (const unsigned char *)dist_tmp, dist, l.nbz, l.nby, l.nbx, l.nblk, B, 2);
@@ -1475,10 +1336,10 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         hipLaunchKernelGGL(k_build_near, dim3((unsigned)((near_waves + 3) / 4)), dim3(256), 0, s0, mask64, (const unsigned char *)dist,
                            near2, dimz, dimy, dimx, l.nbz, l.nby, l.nbx, l.nblk, B);
         sp.end();
-        if (pipe && !fused) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
+        if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
     }
 
-    if (pipe && !fused) {
+    if (pipe) {
         VP_HIP(hipEventRecord(ps->entry, s0));
         // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
         if (ps->used[q]) VP_HIP(hipStreamWaitEvent(s1, ps->call_done[q], 0));
@@ -1495,52 +1356,27 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
         sp.end();
     }
-    FirstHitArgs fa;
-    fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
-    fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
-    fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status;
-    if (!fused) {
+    {
+        FirstHitArgs fa;
+        fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
+        fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
+        fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status;
+        const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
         ProfSpan sp; sp.begin(1, s1);
-#define FH_ARGS fa, p
-        const size_t lds_bytes = (size_t(l.nblk) + 15) & ~size_t(15);
-        // Variants kept for A/B runs: distance field staged in LDS by 32x32-pixel workgroups
-        // (VOXPROJ_LDS_DIST=1) and persistent tile workers (VOXPROJ_FH_WORKERS=n).  Measured on R2 the plain
-        // 16x16-pixel grid reading the tables through L2 is the fastest both alone and beside the gather.
-        const bool lds_ok = lds_bytes <= 80 * 1024 && getenv("VOXPROJ_LDS_DIST");
-        int n_workers = 0;
-        if (const char *e = getenv("VOXPROJ_FH_WORKERS")) n_workers = atoi(e);
         if (flags & VP_FLAG_EXACT_MARCH) {
-            hipLaunchKernelGGL((k_first_hit<0, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), 0, s1, FH_ARGS);
-        } else if (pipe && n_workers > 0) {
-            const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
-            const long long n_tiles = (long long)tiles_x * tiles_y * B * V;
-            if (n_tiles >= (1ll << 31)) return fail(VP_EINVAL, "too many pixel tiles");
-            hipLaunchKernelGGL(k_first_hit_workers, dim3(n_workers), dim3(256), 0, s1, fa, p, tiles_x, tiles_y, (int)n_tiles,
-                               status + ST_TILE);
-        } else if (lds_ok) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                VP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_first_hit<2, 4, 4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
-            size_t lds_req = lds_bytes;
-            if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = std::max(lds_req, size_t(atoi(e)) * 1024);
-            if (lds_req > 160 * 1024) lds_req = 160 * 1024;
-            hipLaunchKernelGGL((k_first_hit<2, 4, 4>), dim3((W + 31) / 32, (H + 31) / 32, B * V), dim3(1024), lds_req, s1, FH_ARGS);
+            hipLaunchKernelGGL(k_first_hit<0>, grid, dim3(256), 0, s1, fa, p);
         } else {
             // Occupancy shaping for the pipelined mode: a 41-KiB dynamic-LDS reservation (the kernel does not touch
             // it) admits at most 3 march workgroups = 12 wavefronts per CU.  Spread that thin the march still
             // finishes under the gather of the previous call (40 ms vs 50 ms per R2 pass) and costs the gather
-            // ~1 % instead of ~8 % (measured: 54.2 -> 52.0 ms per pass); alone it runs unrestricted.
+            // ~1 % instead of ~8 % (measured: mean 55.3 -> 53.5 ms per pass); alone it runs unrestricted.
             size_t lds_req = pipe ? 41 * 1024 : 0;
             if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
-            hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3((W + 15) / 16, (H + 15) / 16, B * V), dim3(256), lds_req, s1, FH_ARGS);
+            hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
-#undef FH_ARGS
         sp.end();
     }
-    if (pipe && !fused) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
+    if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
 
     // ---- phase 2 ----
     GatherArgs g;
@@ -1548,87 +1384,37 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
-    if (fused) {
-        // one launch: gather of the previous pipelined call (if any) + ray-march of this one
-        const int fgx = (W + 15) / 16, fgy = (H + 15) / 16;
-        if (ps->pending) {
-            const GatherArgs &pg = *ps->pend_g;
-            const Params &pp = *ps->pend_p;
-            {
-                ProfSpan sp; sp.begin(3, s0);
-                VP_DISPATCH_KVU(k_gather_heavy, ps->pend_vec_ok, pp.C, dim3(HEAVY_BLOCKS), dim3(GW * 64), 0, s0, pg, pp);
-                sp.end();
-            }
-            const long long n_g = (pp.n_rows - 1 + 3) / 4;
-            int n_workers = 512;                 // 2 workgroups (8 march waves) per CU on 256 CUs
-            if (const char *e = getenv("VOXPROJ_FH_WORKERS")) n_workers = atoi(e) > 0 ? atoi(e) : n_workers;
-            const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
-            const long long n_tiles = (long long)tiles_x * tiles_y * B * V;
-            if (n_g + n_workers >= (1ll << 31) || n_tiles >= (1ll << 31)) return fail(VP_EINVAL, "grid too large");
-            ProfSpan sp; sp.begin(2, s0);
-            VP_DISPATCH_KVU(k_fused, ps->pend_vec_ok, pp.C, dim3((unsigned)(n_g + n_workers)), dim3(256), 0, s0, pg, pp,
-                            fa, p, n_workers, tiles_x, tiles_y, (int)n_tiles, status + ST_TILE);
-            sp.end();
-        } else {
-            ProfSpan sp; sp.begin(1, s0);
-            hipLaunchKernelGGL((k_first_hit<1, 2, 2>), dim3(fgx, fgy, B * V), dim3(256), 0, s0, fa, p);
-            sp.end();
-        }
-        if (!ps->pend_g) { ps->pend_g = new GatherArgs(); ps->pend_p = new Params(); }
-        *ps->pend_g = g;
-        *ps->pend_p = p;
-        ps->pend_vec_ok = vec_ok;
-        ps->pending = true;
-        ps->last_q = q;
-        ps->calls++;
-        VP_HIP(hipGetLastError());
-        return VP_OK;
-    }
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
-    const int blocks_h = 128;
-    // A/B knob: a dynamic-LDS reservation caps the gather's workgroups per CU (no gain measured once the
-    // march's atomics were aggregated; default off).
-    size_t glds = 0;
-    if (const char *e = getenv("VOXPROJ_GATHER_LDS_KB")) glds = size_t(atoi(e)) * 1024;
-#define LAUNCH_GATHER(KERNEL, BLOCKS, THREADS, STREAM) \
-    VP_DISPATCH_KVU(KERNEL, vec_ok, C, dim3(BLOCKS), dim3(THREADS), glds, STREAM, g, p)
+    // heavy voxels: beside the normal gather on a third stream when pipelined (they write output rows, so they follow
+    // everything the caller queued before this call and the previous call's gather), else in front of it
+    hipStream_t sh = pipe ? ps->side2 : s0;
     if (pipe) {
-        // heavy voxels on the side stream, next to the normal gather.  They write output rows, so they must
-        // follow everything the caller queued before this call and the previous call's gather.
-        hipStream_t s2 = ps->side2;
-        VP_HIP(hipStreamWaitEvent(s2, ps->entry, 0));
-        VP_HIP(hipStreamWaitEvent(s2, ps->fh_done[q], 0));
-        {
-            ProfSpan sp; sp.begin(3, s2);
-            LAUNCH_GATHER(k_gather_heavy, blocks_h, GW * 64, s2);
-            sp.end();
-        }
-        VP_HIP(hipEventRecord(ps->heavy_done[q], s2));
+        VP_HIP(hipStreamWaitEvent(sh, ps->entry, 0));
+        VP_HIP(hipStreamWaitEvent(sh, ps->fh_done[q], 0));
+    }
+    {
+        ProfSpan sp; sp.begin(3, sh);
+        VP_DISPATCH_KVU(k_gather_heavy, vec_ok, C, dim3(HEAVY_BLOCKS), dim3(GW * 64), 0, sh, g, p);
+        sp.end();
+    }
+    if (pipe) {
+        VP_HIP(hipEventRecord(ps->heavy_done[q], sh));
         VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
-        if (blocks_n > 0) {
-            ProfSpan sp; sp.begin(2, s0);
-            LAUNCH_GATHER(k_gather, blocks_n, 256, s0);
-            sp.end();
-        }
+    }
+    if (blocks_n > 0) {
+        ProfSpan sp; sp.begin(2, s0);
+        VP_DISPATCH_KVU(k_gather, vec_ok, C, dim3(blocks_n), dim3(256), 0, s0, g, p);
+        sp.end();
+    }
+    if (pipe) {
         VP_HIP(hipStreamWaitEvent(s0, ps->heavy_done[q], 0));
         VP_HIP(hipEventRecord(ps->call_done[q], s0));
         ps->used[q] = true;
         ps->last_q = q;
         ps->calls++;
-    } else {
-        {
-            ProfSpan sp; sp.begin(3, s0);
-            LAUNCH_GATHER(k_gather_heavy, blocks_h, GW * 64, s0);
-            sp.end();
-        }
-        if (blocks_n > 0) {
-            ProfSpan sp; sp.begin(2, s0);
-            LAUNCH_GATHER(k_gather, blocks_n, 256, s0);
-            sp.end();
-        }
-        if (ps) ps->last_q = 0;
+    } else if (ps) {
+        ps->last_q = 0;
     }
-#undef LAUNCH_GATHER
     VP_HIP(hipGetLastError());
     if (flags & VP_FLAG_SYNC) return vp_workspace_status(workspace, stream_);
     return VP_OK;
@@ -1658,8 +1444,6 @@ int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const flo
 static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WORDS] */)
 {
     if (PipeState *ps = pipe_state(workspace, false)) {
-        int rc_ = flush_pending(ps, stream);
-        if (rc_ != VP_OK) return rc_;
         VP_HIP(hipStreamSynchronize(ps->side));
         VP_HIP(hipStreamSynchronize(ps->side2));
     }
@@ -1688,20 +1472,6 @@ int vp_stream_read(const float *src, int64_t n_floats, float *sink, void *stream
     hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream_, src, (long long)(n_floats / 4), sink);
     VP_HIP(hipGetLastError());
     return VP_OK;
-}
-
-int vp_debug_spin(int mode, int blocks, int iters, const int32_t *table, int table_n, int32_t *sink, void *stream_)
-{
-    hipLaunchKernelGGL(k_debug_spin, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, mode, iters, (const int *)table,
-                       table_n, (int *)sink);
-    VP_HIP(hipGetLastError());
-    return VP_OK;
-}
-
-int vp_workspace_flush(void *workspace, void *stream_)
-{
-    if (!workspace) return fail(VP_EINVAL, "null workspace");
-    return flush_pending(pipe_state(workspace, false), (hipStream_t)stream_);
 }
 
 int vp_workspace_status(void *workspace, void *stream_)
@@ -1805,7 +1575,6 @@ int vp_workspace_release(void *workspace)
     for (size_t i = 0; i < g_pipes.size(); i++)
         if (g_pipes[i].first == workspace) {
             PipeState *ps = g_pipes[i].second;
-            if (ps->pending) (void)flush_pending(ps, nullptr);   // callers should have drained via vp_workspace_status
             (void)hipStreamSynchronize(ps->side);
             (void)hipStreamSynchronize(ps->side2);
             (void)hipStreamDestroy(ps->side);
@@ -1816,8 +1585,6 @@ int vp_workspace_release(void *workspace)
                 (void)hipEventDestroy(ps->call_done[q]);
             }
             (void)hipEventDestroy(ps->entry);
-            delete ps->pend_g;
-            delete ps->pend_p;
             delete ps;
             g_pipes.erase(g_pipes.begin() + i);
             break;

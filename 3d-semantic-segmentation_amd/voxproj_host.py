@@ -24,8 +24,8 @@ _lock = threading.Lock()
 EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
-    "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors", "vp_workspace_flush",
-    "vp_debug_spin", "vp_project_features_f16", "vp_nearest_voxel",
+    "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors",
+    "vp_project_features_f16", "vp_nearest_voxel",
     "vp_stream_read",
 ]
 
@@ -70,8 +70,6 @@ def lib():
                                            ctypes.c_int, ctypes.c_int, vp, ctypes.c_int64, vp, vp]
             L.vp_workspace_status.restype = ctypes.c_int
             L.vp_workspace_status.argtypes = [vp, vp]
-            L.vp_workspace_flush.restype = ctypes.c_int
-            L.vp_workspace_flush.argtypes = [vp, vp]
             L.vp_workspace_counters.restype = ctypes.c_int
             L.vp_workspace_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, vp]
             L.vp_copy_hit_image.restype = ctypes.c_int
@@ -114,8 +112,7 @@ class Workspace:
         import torch
         if self.buf is None or self.buf.numel() < nbytes + 256 or self.buf.device != device:
             if self.buf is not None:
-                # growing while pipelined calls are in flight: finish them (the last call's gather may still
-                # be owed) before the old buffer goes away
+                # growing while pipelined calls may be in flight: finish them before the old buffer goes away
                 import torch as _t
                 check(lib().vp_workspace_status(self.ptr(), _t.cuda.current_stream(self.buf.device).cuda_stream))
             self.release()
@@ -236,13 +233,6 @@ def profile_read():
     return dict(prep_ms=ms[0], first_hit_ms=ms[1], gather_ms=ms[2], heavy_ms=ms[3],
                 prep_launches=int(n[0]), first_hit_launches=int(n[1]), gather_launches=int(n[2]),
                 heavy_launches=int(n[3]))
-
-
-def workspace_flush(ws, device):
-    """Pipelined mode: launch the gather still owed by the last call (asynchronous, stream-ordered)."""
-    import torch
-    if ws.buf is not None:
-        check(lib().vp_workspace_flush(ws.ptr(), torch.cuda.current_stream(device).cuda_stream))
 
 
 def workspace_status(ws, device):

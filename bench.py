@@ -191,7 +191,6 @@ def main():
         o.zero_()
         for ci in range(len(calls)):
             one_call(ci, o=o, c=c)
-        voxproj_host.workspace_flush(ws, dev)      # pipelined mode: the last call's gather is part of the pass
         if dist is not None:
             if a.no_overlap_reduce:
                 reduce_partials(dist, [o, c])

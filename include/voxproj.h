@@ -44,14 +44,14 @@ enum {
                                 rebuilding them                                                    */
     VP_FLAG_EXACT_MARCH = 4, /* A/B arm: evaluate every ray sample like K.cu:47-82 does instead of
                                 leaping over provably empty space (same results, slower)           */
-    VP_FLAG_PIPELINE = 8     /* asynchronous job mode (excludes VP_FLAG_SYNC): this call launches its own
-                                phase 1 (ray-march) FUSED with the gather that the previous pipelined call
-                                on the same workspace still owes -- one kernel whose workgroups alternate
-                                between the two roles -- so the issue-bound march and the HBM-bound gather
-                                share every CU.  The outputs of call j are therefore complete only after
-                                call j+1 or vp_workspace_status(), which launches the last owed gather.
-                                The caller keeps ALL arguments of a call (feats, occ, vmi, intr, count, out,
-                                views_hit) alive and unchanged until then, and uses one stream per
+    VP_FLAG_PIPELINE = 8     /* asynchronous job mode (excludes VP_FLAG_SYNC): phase 1 (ray-march) runs on a
+                                library-owned side stream -- held to a few wavefronts per CU -- so that the
+                                march of this call overlaps the gather of the previous call on the same
+                                workspace (two buffer sets alternate; heavy voxels on a third stream).  The
+                                gather and every write to count/out/views_hit stay on `stream`, in order.
+                                The caller promises that occ, vmi and intr are not being written by work
+                                still pending on `stream`, keeps them alive and unchanged until the stream
+                                has been synchronised (vp_workspace_status does), and uses one stream per
                                 workspace.                                                            */
 };
 
@@ -123,12 +123,6 @@ int vp_nearest_voxel(const float *pts_sorted, const int32_t *perm, const int32_t
 int vp_stream_read(const float *src, int64_t n_floats, float *sink, void *stream);
 
 /*
- * Diagnostic co-runner used by tools/dbg_corun.py to study what slows the gather when another kernel shares
- * the GPU (mode 0 pure VALU, 1 dependent scattered L2 loads, 2 returning integer atomics).  Not a product path.
- */
-int vp_debug_spin(int mode, int blocks, int iters, const int32_t *table, int table_n, int32_t *sink, void *stream);
-
-/*
  * Same as vp_project_features with the feature maps stored as IEEE binary16 [B,V,H,W,C] (C % 8 == 0).
  * LSeg features are fp16 at rest (script/extract_lseg_features.py:97) and
  * prepare_tensor_data.py:126 casts the resized maps back to fp16 before widening them, so every value the
@@ -144,13 +138,6 @@ int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const flo
                             int dimz, int dimy, int dimx, int64_t n_rows,
                             void *workspace, size_t workspace_bytes,
                             void *stream, int flags);
-
-/*
- * Pipelined mode: launches, on `stream`, the gather that the last VP_FLAG_PIPELINE call on this workspace
- * still owes (no-op otherwise).  Asynchronous; after it the outputs of every call made so far are ordered
- * on `stream` like any other work.
- */
-int vp_workspace_flush(void *workspace, void *stream);
 
 /*
  * Reads back and clears the device-side status word of a workspace after the stream has been
@@ -203,9 +190,8 @@ int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx,
                       int64_t n_rows, int view_base, int32_t *status_dev, void *stream);
 
 /*
- * Forgets the state the library keeps for a workspace that was used with VP_FLAG_PIPELINE (call
- * vp_workspace_status first -- the last pipelined call's gather is launched there -- then this,
- * before freeing or recycling the workspace memory).
+ * Forgets the side streams / events the library keeps for a workspace that was used with
+ * VP_FLAG_PIPELINE (drains them first); call before freeing or recycling the workspace memory.
  */
 int vp_workspace_release(void *workspace);
 

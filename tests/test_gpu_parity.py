@@ -381,7 +381,6 @@ def test_march_ab_arm_exact_loop_equals_leaping(oracle_mod, monkeypatch):
     monkeypatch.setenv("VOXPROJ_EXACT_MARCH", "1")
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
     monkeypatch.delenv("VOXPROJ_EXACT_MARCH")
-    monkeypatch.setenv("VOXPROJ_LDS_DIST", "1")
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
 
 
@@ -404,10 +403,9 @@ def test_ray_parameter_closed_form_over_many_increments(oracle_mod):
             _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, opts, np.array([-2.1, -1.7, 0.05], np.float32), 0.2, 151)
 
 
-@pytest.mark.parametrize("env", [{"VOXPROJ_PIPE": "fused"}, {"VOXPROJ_FH_WORKERS": "64"}, {"VOXPROJ_LDS_DIST": "1"},
-                                 {"VOXPROJ_GATHER_LDS_KB": "40"}])
-def test_pipelining_ab_arms_stay_exact(oracle_mod, monkeypatch, env):
-    # the alternative pipelining structures kept for A/B measurements must give the same bits
+@pytest.mark.parametrize("env", [{}, {"VOXPROJ_FH_LDS_KB": "0"}, {"VOXPROJ_FH_LDS_KB": "80"}])
+def test_pipelined_occupancy_knob_stays_exact(oracle_mod, monkeypatch, env):
+    # the march's occupancy cap in pipelined mode (a dynamic-LDS reservation) is a scheduling hint only
     import voxproj_host
     for k, v in env.items():
         monkeypatch.setenv(k, v)
