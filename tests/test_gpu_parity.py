@@ -508,3 +508,47 @@ def test_increment_too_small_to_advance_raises_instead_of_hanging(oracle_mod):
     opts = np.array([16, 8, 0.01, 10.0, 1e-8], np.float32)
     with pytest.raises(RuntimeError, match="never terminate"):
         _gpu_call(feats, s.occ[None], s.c2w, s.intr, opts, s.grid_origin, s.voxel_size, count_t, out_t)
+
+
+def _random_rotation(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def test_randomized_differential_against_the_oracle(oracle_mod):
+    # 80 random configurations: grid shape and density, voxel size, origin, free camera poses (inside and outside the
+    # grid, any orientation), intrinsics, image size, ray range and increment, channel count, views per call
+    rng = np.random.default_rng(2025)
+    n_hit_cases = 0
+    for case in range(80):
+        dims = rng.integers(3, 40, 3)                      # Z, Y, X
+        dens = float(np.exp(rng.uniform(np.log(0.002), np.log(0.35))))
+        occ = np.zeros(dims, np.int32)
+        n = max(1, int(occ.size * dens))
+        idx = rng.choice(occ.size, n, replace=False)
+        occ.reshape(-1)[idx] = rng.permutation(n) + 1
+        vs = float(np.float32(np.exp(rng.uniform(np.log(0.02), np.log(0.5)))))
+        origin = rng.uniform(-3, 3, 3).astype(np.float32)
+        ext = dims[::-1] * vs                               # x, y, z extent
+        V = int(rng.integers(1, 5))
+        W, H = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        C = int(rng.choice([1, 4, 5, 8, 16, 36]))
+        c2w = np.zeros((V, 4, 4), np.float32)
+        for v in range(V):
+            c2w[v, :3, :3] = _random_rotation(rng)
+            c2w[v, :3, 3] = origin + rng.uniform(-0.6, 1.6, 3) * ext
+            c2w[v, 3, 3] = 1
+        f = float(rng.uniform(0.4, 2.5)) * W
+        intr = np.array([f, f * rng.uniform(0.8, 1.25), rng.uniform(0.2, 0.8) * W, rng.uniform(0.2, 0.8) * H], np.float32)
+        dmin = float(rng.choice([0.0, 0.01, 0.3]))
+        dmax = float(rng.uniform(0.5, 3.0) * np.linalg.norm(ext))
+        inc = float(np.float32(vs * np.exp(rng.uniform(np.log(0.15), np.log(2.0)))))
+        opts = np.array([W, H, dmin, dmax, inc], np.float32)
+        feats = rng.standard_normal((1, V, H, W, C)).astype(np.float32)
+        r, _, _ = _compare(oracle_mod, feats, occ[None], c2w, intr, opts, origin, vs, n + 1, expect_boxmiss=None)
+        n_hit_cases += int((r["hits"] > 0).any())
+    assert n_hit_cases > 30
