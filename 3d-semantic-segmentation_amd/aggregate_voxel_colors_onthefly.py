@@ -50,3 +50,84 @@ class VoxelColorAggregator:
         xyz = (z[:, [2, 1, 0]].astype(np.int64) * self.voxel_size + np.array(self.grid_origin, dtype=np.float64))
         return dict(xyz=torch.from_numpy(xyz.astype(np.float32)), avg_color=avg.cpu(),
                     hit_count=self.hits[ids].long().cpu(), voxel_coords=torch.from_numpy(z.astype(np.int32)))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# entry point (reference: the top-level script body of aggregate_voxel_colors_onthefly.py:13-220)
+# ----------------------------------------------------------------------------------------------------------
+CHECKPOINT_DIR = "voxel_color_checkpoints"          # AGGC:17
+CHECKPOINT_EVERY = 50                               # AGGC:145
+
+
+def main(argv=None):
+    import argparse
+    import glob
+    import os
+
+    from PIL import Image
+
+    import build_sparse_occupancy as bso
+    import prepare_tensor_data as ptd
+
+    ap = argparse.ArgumentParser(description="Aggregate voxel colors pipeline")
+    ap.add_argument("--first_only", action="store_true", help="Only process the first input image for debug")
+    ap.add_argument("--lseg_dir", default=os.environ.get("LSEG_DIR", "lseg_embed_features/features"),
+                    help="the reference enumerates the views through the feature files (AGGC:62)")
+    ap.add_argument("--images_dir", default=os.environ.get("IMAGES_DIR", "images"))
+    ap.add_argument("--cam_params", default=os.environ.get("CAM_PARAMS", "camera_params/camera_params.json"))
+    ap.add_argument("--voxel_ply", default=os.environ.get("VOXEL_PLY", "minkowski_grid.ply"))
+    ap.add_argument("--checkpoint_dir", default=os.environ.get("CHECKPOINT_DIR", CHECKPOINT_DIR))
+    ap.add_argument("--views_per_call", type=int, default=32)
+    args = ap.parse_args(argv)
+    os.makedirs(args.checkpoint_dir, exist_ok=True)
+
+    voxel_size, grid_origin, grid_shape, n_from_name = bso.extract_voxel_params(args.voxel_ply)      # AGGC:24-59
+    num_voxels = n_from_name if n_from_name is not None else (int(np.prod(grid_shape)) if grid_shape else "unknown")
+    feature_files = sorted(glob.glob(os.path.join(args.lseg_dir, "*.npy")))                          # AGGC:62
+    if not feature_files:
+        raise RuntimeError(f"No .npy feature files found in {args.lseg_dir}")
+    if args.first_only:
+        feature_files = feature_files[:1]
+    occ = bso.build_occupancy(bso.read_voxel_ply(args.voxel_ply), grid_origin, voxel_size, device="cuda")
+    by_name, cams = ptd.load_camera_params(args.cam_params)
+    agg = VoxelColorAggregator(occ, grid_origin, voxel_size)
+
+    def save(idx, final):
+        r = agg.result()
+        if r["xyz"].shape[0] == 0:
+            return
+        name = (f"ALL_nonzero_voxel_colors_{idx}_vox{num_voxels}.pt" if final else f"checkpoint_voxel_colors_{idx}.pt")
+        torch.save(r, os.path.join(args.checkpoint_dir, name))                                       # AGGC:173-179,212-218
+
+    imgs, c2ws, intrs, idx = [], [], [], 0
+
+    def flush():
+        if imgs:
+            agg.add_views(torch.from_numpy(np.stack(imgs)), torch.stack(c2ws), torch.stack(intrs))
+            imgs.clear(); c2ws.clear(); intrs.clear()
+
+    for k, fpath in enumerate(feature_files):
+        base = os.path.basename(fpath)[:-4]
+        img_path = next((c for c in (os.path.join(args.images_dir, base + e) for e in ("", ".jpg", ".JPG", ".png", ".PNG"))
+                         if os.path.exists(c)), None)                                                # AGGC:85-99
+        entry = by_name.get(base)
+        if img_path is None or entry is None:
+            print(f"[WARN] No image file or camera entry found for {base}")
+            continue
+        img = np.array(Image.open(img_path).convert("RGB"))                                          # AGGC:100-101
+        if imgs and img.shape != imgs[0].shape:
+            flush()
+        intr, c2w = ptd.camera_for(entry, cams, None)                                                # PTDC: unscaled intrinsics
+        imgs.append(img); c2ws.append(c2w); intrs.append(intr)
+        idx = k + 1
+        if len(imgs) >= args.views_per_call or idx % CHECKPOINT_EVERY == 0:
+            flush()
+        if idx % CHECKPOINT_EVERY == 0:                                                              # AGGC:145
+            save(idx, final=False)
+    flush()
+    save(idx, final=True)
+    print(f"[DONE] COLOR PROJECTION PIPELINE COMPLETED. Checkpoint directory: {args.checkpoint_dir}")
+
+
+if __name__ == "__main__":
+    main()

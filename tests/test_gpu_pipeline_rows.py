@@ -205,3 +205,61 @@ def test_nearest_voxel_map_matches_reference_kdtree():
     assert np.array_equal(d_got, d_ref)
     assert len(diff) < 0.01 * len(ref)
     assert np.array_equal(got[-300:], np.arange(300))            # centres sitting exactly on voxels map to them
+
+
+def test_color_entry_point_end_to_end(tmp_path, oracle_mod):
+    # aggregate_voxel_colors_onthefly.main() on files: PLY + camera JSON + PNG images (+ empty .npy names, AGGC:62)
+    import json
+
+    from PIL import Image
+
+    import aggregate_voxel_colors_onthefly as aggc
+    from synthetic_scene import make_scene
+    s = make_scene(1500, 3, 60, 40, seed=92, room=(5.0, 4.0, 2.4))
+    ply = tmp_path / f"scene_{s.n_vox}vox_grid.ply"
+    with open(ply, "w") as f:
+        f.write("ply\nformat ascii 1.0\n")
+        f.write(f"comment voxel_size {s.voxel_size!r}\ncomment grid_origin {float(s.grid_origin[0])!r} "
+                f"{float(s.grid_origin[1])!r} {float(s.grid_origin[2])!r}\n")
+        f.write(f"element vertex {s.n_vox}\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for q in s.points:
+            f.write(f"{float(q[0])!r} {float(q[1])!r} {float(q[2])!r}\n")
+    (tmp_path / "features").mkdir()
+    (tmp_path / "images").mkdir()
+    rng = np.random.default_rng(92)
+    images, imgs = {}, []
+    for v in range(3):
+        name = f"IMG{v:03d}"
+        np.save(tmp_path / "features" / f"{name}.npy", np.zeros((1, 1, 1), np.float16))
+        img = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+        Image.fromarray(img).save(tmp_path / "images" / f"{name}.png")
+        imgs.append(img)
+        c2w = s.c2w[v].astype(np.float64)
+        R = c2w[:3, :3].T
+        images[str(v)] = {"name": name, "camera_id": 1, "R": R.tolist(), "tvec": (-R @ c2w[:3, 3]).tolist()}
+    cam_json = tmp_path / "cams.json"
+    cam_json.write_text(json.dumps({"images": images, "cameras": {"1": {"params": [float(x) for x in s.intr]}}}))
+    out_dir = tmp_path / "out"
+    aggc.main(["--lseg_dir", str(tmp_path / "features"), "--images_dir", str(tmp_path / "images"), "--cam_params", str(cam_json),
+               "--voxel_ply", str(ply), "--checkpoint_dir", str(out_dir), "--views_per_call", "2"])
+    r = torch.load(out_dir / f"ALL_nonzero_voxel_colors_3_vox{s.n_vox}.pt")
+    assert set(r) == {"xyz", "avg_color", "hit_count", "voxel_coords"}
+    # the same aggregate from the oracle's per-view RGB projection (dict semantics of AGGC:134-140,182-186)
+    import build_sparse_occupancy as bso
+    occ = bso.build_occupancy(bso.read_voxel_ply(str(ply)), [float(x) for x in s.grid_origin], s.voxel_size).numpy()
+    sums, counts = {}, {}
+    for v in range(3):
+        R = np.array(images[str(v)]["R"], np.float32)
+        t = np.array(images[str(v)]["tvec"], np.float32)
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[:3, :3] = R.T
+        c2w[:3, 3] = -R.T @ t                                  # prepare_tensor_data.py:165-172
+        col, zyx, _ = oracle_mod.rgb_project(occ, c2w, s.intr, s.grid_origin, float(s.voxel_size), imgs[v])
+        for k, c in zip(map(tuple, zyx.tolist()), col):
+            sums[k] = c.copy() if k not in sums else (sums[k] + c).astype(np.float32)
+            counts[k] = counts.get(k, 0) + 1
+    keys = list(sums)
+    assert np.array_equal(r["voxel_coords"].numpy(), np.array(keys, np.int32))
+    assert np.array_equal(r["hit_count"].numpy(), np.array([counts[k] for k in keys]))
+    exp = np.stack([sums[k] / np.float32(counts[k]) for k in keys]).astype(np.float32)
+    assert r["avg_color"].numpy().tobytes() == exp.tobytes()
