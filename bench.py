@@ -99,6 +99,28 @@ def cpu_baseline(scene, C, n_views, n_threads):
                        f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices)")
 
 
+def cpu_torch_loop(scene, n_views, n_threads):
+    """The reference's only CPU projection loop (debug_project_features.py:59-84: every occupied voxel centre
+    through the pinhole model, in-front and in-image tests) as the vectorised torch-CPU expression of
+    debug_project_features.voxel_centre_diagnostics -- no occlusion test, no feature gather, so it is NOT the
+    same work as the projector; reported beside cpu_baseline because north_star names it."""
+    from debug_project_features import voxel_centre_diagnostics
+    torch.set_num_threads(n_threads)
+    occ = torch.from_numpy(scene.occ)
+    c2w = torch.from_numpy(scene.c2w)
+    intr = torch.from_numpy(scene.intr)
+    origin = torch.from_numpy(np.asarray(scene.grid_origin, dtype=np.float32))
+    voxel_centre_diagnostics(occ, c2w[0], intr, origin, scene.voxel_size, scene.width, scene.height)   # warm
+    t0 = time.perf_counter()
+    inb = 0
+    for v in range(n_views):
+        inb += voxel_centre_diagnostics(occ, c2w[v], intr, origin, scene.voxel_size, scene.width, scene.height)["n_in_bounds"]
+    dt = time.perf_counter() - t0
+    return dict(value=round(scene.n_vox * n_views / dt / 1e6, 3), unit="Mvoxel-views/s", cores=n_threads,
+                what="voxel-centre projection + bounds test only (DPF:59-84), float64 torch-CPU, vectorised",
+                sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {inb} centres in bounds")
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -289,6 +311,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)
             ncores = os.cpu_count() or 1
             res["cpu_baseline"] = cpu_baseline(scene, C, min(a.cpu_views, n_views), ncores)
+            res["cpu_torch_loop"] = cpu_torch_loop(scene, min(16, n_views), ncores)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
