@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="plain calls: phase 1 and 2 serial on one stream")
-    ap.add_argument("--cpu-views", type=int, default=4, help="views in the cpu_baseline sample")
+    ap.add_argument("--cpu-views", type=int, default=8, help="views in the cpu_baseline sample")
     ap.add_argument("--dtype", default="f32", choices=("f32", "f16"), help="feature-map storage type; f32 is the "
                     "BASELINE metric config, f16 the lossless half-bandwidth mode of SURVEY 8f/n4 (extra, not the headline)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
@@ -81,6 +81,20 @@ def pmc_traffic(workload, chunk):
     return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / prof["views_per_call"]
 
 
+def host_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (a one-GPU box of
+    the pool shows 256 logical CPUs but grants 16; 256 OpenMP threads on that share run the oracle 7x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(scene, C, n_views, n_threads):
     """Time the CPU oracle (port of project_image_cuda_kernel.cu:24-92,157-187) on n_views views."""
     from oracle import oracle
@@ -94,9 +108,10 @@ def cpu_baseline(scene, C, n_views, n_threads):
     oracle.project_features(feats, occ, scene.c2w[:n_views].reshape(-1), scene.intr[None], scene.opts(),
                             scene.grid_origin, scene.voxel_size, count, out, want_hits=False, nthreads=n_threads)
     dt = time.perf_counter() - t0
-    return dict(value=scene.n_vox * n_views / dt / 1e6, unit="Mvoxel-views/s", cores=n_threads, kind="port",
+    return dict(value=round(scene.n_vox * n_views / dt / 1e6, 4), unit="Mvoxel-views/s", cores=n_threads, kind="port",
                 sample=f"{n_views} of the workload's views at full resolution, all {scene.n_vox} voxels, "
-                       f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices)")
+                       f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices; {os.cpu_count()} logical CPUs "
+                       f"visible, {n_threads} granted to this process)")
 
 
 def cpu_torch_loop(scene, n_views, n_threads):
@@ -309,7 +324,7 @@ def main():
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)
-            ncores = os.cpu_count() or 1
+            ncores = host_cores()
             res["cpu_baseline"] = cpu_baseline(scene, C, min(a.cpu_views, n_views), ncores)
             res["cpu_torch_loop"] = cpu_torch_loop(scene, min(16, n_views), ncores)
         print(json.dumps(res), flush=True)

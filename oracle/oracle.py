@@ -38,6 +38,20 @@ def lib():
     return _lib
 
 
+def host_cores():
+    """Threads worth starting: the affinity mask capped by the cgroup CPU quota (containers often show every
+    logical CPU of the host but grant a fraction; oversubscribed OpenMP teams run several times slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _p(a, ct):
     return a.ctypes.data_as(ctypes.POINTER(ct)) if a is not None else None
 
@@ -77,7 +91,7 @@ def project_features(feats, occ, vmi, intr, opts, grid_origin, voxel_size, count
         ctypes.c_float(voxel_size), B, V, C, Z, Y, X,
         _p(count, ctypes.c_int32), _p(out, ctypes.c_float), ctypes.c_int64(n_rows),
         _p(hits, ctypes.c_int32), _p(out64, ctypes.c_double), _p(steps, ctypes.c_int32),
-        int(nthreads))
+        int(nthreads) or host_cores())
     return dict(rc=rc, hits=hits, out64=out64, steps=steps)
 
 
@@ -94,7 +108,8 @@ def first_hit(occ, vmi, intr, opts, grid_origin, voxel_size, B, V, want_steps=Fa
     steps = np.zeros((B, V, H, W), np.int32) if want_steps else None
     lib().oracle_first_hit(_p(occ, ctypes.c_int64), _p(vmi, ctypes.c_float), _p(intr, ctypes.c_float),
                            _p(opts, ctypes.c_float), _p(go, ctypes.c_float), ctypes.c_float(voxel_size),
-                           B, V, Z, Y, X, _p(hits, ctypes.c_int32), _p(steps, ctypes.c_int32), int(nthreads))
+                           B, V, Z, Y, X, _p(hits, ctypes.c_int32), _p(steps, ctypes.c_int32),
+                           int(nthreads) or host_cores())
     return (hits, steps) if want_steps else hits
 
 
