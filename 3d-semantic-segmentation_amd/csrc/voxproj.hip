@@ -1370,7 +1370,14 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
             // it) admits at most 3 march workgroups = 12 wavefronts per CU.  Spread that thin the march still
             // finishes under the gather of the previous call (40 ms vs 50 ms per R2 pass) and costs the gather
             // ~1 % instead of ~8 % (measured: mean 55.3 -> 53.5 ms per pass); alone it runs unrestricted.
-            size_t lds_req = pipe ? 41 * 1024 : 0;
+            // Only while the previous call's gather is still queued or running: behind an idle GPU (first call of
+            // a job, or after the caller synchronised) the march has nothing to spare and runs unrestricted.
+            bool beside_gather = false;
+            if (pipe && ps->used[q ^ 1]) {
+                beside_gather = hipEventQuery(ps->call_done[q ^ 1]) == hipErrorNotReady;
+                (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
+            }
+            size_t lds_req = beside_gather ? 41 * 1024 : 0;
             if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
             hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
