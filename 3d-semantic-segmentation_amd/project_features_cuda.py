@@ -15,13 +15,24 @@ Differences from the reference, all fenced in DESIGN.md:
     project_image_cuda.cpp:46 vs kernel.cu:445, and is never used by the pipeline);
   * V is not limited to 16 views per call and feature offsets are 64-bit.
 
+Two fronts over the same C-ABI call, same checks and messages:
+  * ``_project_features_ext`` -- compiled pybind11 module (csrc/project_features_ext.cpp, the counterpart of
+    project_image_cuda.cpp; built by ``voxproj_host.build_ext()``), used whenever it has been built;
+  * ``project_features_cuda_py`` below -- the same front in Python over ctypes, used when the compiled module
+    is absent.  ``IMPLEMENTATION`` says which one ``project_features_cuda`` is.
+
 There is no CPU fallback: without libvoxproj.so or without a GPU tensor the call raises.
 """
 import torch
 
 import voxproj_host as _host
 
-__all__ = ["project_features_cuda"]
+try:
+    import _project_features_ext as _ext      # needs torch imported first (libtorch, libc10_hip)
+except ImportError:                           # not built: the ctypes front below does the same job
+    _ext = None
+
+__all__ = ["project_features_cuda", "project_features_cuda_py", "IMPLEMENTATION", "last_workspace"]
 
 
 def _check(cond, msg):
@@ -35,8 +46,8 @@ def _check_input(t, name):
     _check(t.is_contiguous(), f"{name} must be contiguous")
 
 
-def project_features_cuda(encoded_2d_features, occupancy_3D, viewMatrixInv, intrinsicParams, opts,
-                          mapping2dto3d_num, projected_features, pred_mode_t, grid_origin, voxel_size):
+def project_features_cuda_py(encoded_2d_features, occupancy_3D, viewMatrixInv, intrinsicParams, opts,
+                             mapping2dto3d_num, projected_features, pred_mode_t, grid_origin, voxel_size):
     """Projecting from 2D to 3D: accumulate per-voxel feature sums and pixel hit counts in place.
 
     Arguments exactly as project_image_cuda.cpp:23-33 / project_image_cuda_kernel.cu:374-385:
@@ -98,3 +109,31 @@ def project_features_cuda(encoded_2d_features, occupancy_3D, viewMatrixInv, intr
         [float(v) for v in opts_cpu.tolist()], mapping2dto3d_num, projected_features,
         [float(v) for v in grid_origin[:3].tolist()], float(voxel_size), sync=True)
     return None
+
+
+class _ExtWorkspace:
+    """What voxproj_host.hit_image / counters need to know about the compiled front's scratch buffer."""
+
+    def __init__(self, ptr, shape):
+        self._ptr, self.last_shape = int(ptr), tuple(int(v) for v in shape)
+
+    def ptr(self):
+        return self._ptr
+
+
+def last_workspace(device, front=None):
+    """Test/diagnostic hook: the scratch buffer of the last call on ``device`` (for voxproj_host.hit_image and
+    voxproj_host.counters).  ``front``: "compiled" / "python", default the one ``project_features_cuda`` is."""
+    device = torch.device(device)
+    if (front or IMPLEMENTATION) == "compiled":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return _ExtWorkspace(*_ext.last_call(idx))
+    return _host.get_workspace(device)
+
+
+if _ext is not None:
+    project_features_cuda = _ext.project_features_cuda
+    IMPLEMENTATION = "compiled"
+else:
+    project_features_cuda = project_features_cuda_py
+    IMPLEMENTATION = "python"

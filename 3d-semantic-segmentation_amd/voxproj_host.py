@@ -44,6 +44,38 @@ def build(force=False):
     return LIB_PATH
 
 
+EXT_PATH = os.path.join(_HERE, "_project_features_ext.so")
+
+
+def build_ext(force=False):
+    """Compile the pybind11 front of the drop-in module (csrc/project_features_ext.cpp, the counterpart of the
+    reference's project_image_cuda.cpp) against this interpreter's torch: hipcc as a host C++17 compiler, linked
+    to libvoxproj.so beside it.  Returns the path of _project_features_ext.so."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    build()
+    src = os.path.join(_HERE, "csrc", "project_features_ext.cpp")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "voxproj.h")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+    if not force and os.path.exists(EXT_PATH) and os.path.getmtime(EXT_PATH) >= newest:
+        return EXT_PATH
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["hipcc", "-std=c++17", "-O2", "-fPIC", "-shared", "-w", src, "-o", EXT_PATH,
+           "-I" + os.path.join(os.path.dirname(_HERE), "include"), "-I" + sysconfig.get_paths()["include"]]
+    cmd += ["-I" + p for p in cpp_extension.include_paths()]
+    cmd += ["-DTORCH_EXTENSION_NAME=_project_features_ext", "-DTORCH_API_INCLUDE_EXTENSION_H", "-DUSE_ROCM",
+            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi())]
+    for name in ("_PYBIND11_COMPILER_TYPE", "_PYBIND11_STDLIB", "_PYBIND11_BUILD_ABI"):
+        val = getattr(torch._C, name, None)
+        if val is not None:
+            cmd.append('-DPYBIND11%s="%s"' % (name[len("_PYBIND11"):], val))
+    cmd += ["-L" + torch_lib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+            "-L" + _HERE, "-lvoxproj", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib]
+    subprocess.check_call(cmd)
+    return EXT_PATH
+
+
 def lib():
     """Load the shared library (dlopen only; no device call is made here)."""
     global _lib
@@ -142,6 +174,7 @@ _workspaces = {}
 
 
 def get_workspace(device):
+    """The ctypes front's per-device workspace (project_features_cuda.last_workspace covers both fronts)."""
     key = (device.type, device.index)
     ws = _workspaces.get(key)
     if ws is None:

@@ -45,16 +45,33 @@ def _args(device="cpu"):
             torch.zeros(3, C, device=device), torch.tensor([False]), torch.zeros(3), 1.0]
 
 
-def test_wrapper_rejects_cpu_tensors_like_check_cuda():
+TEN = ["encoded_2d_features", "occupancy_3D", "viewMatrixInv", "intrinsicParams", "opts",
+       "mapping2dto3d_num", "projected_features", "pred_mode_t", "grid_origin", "voxel_size"]
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    """The drop-in module with its compiled pybind11 front built (hipcc as host compiler, ~1 min the first time)."""
+    import voxproj_host
+    voxproj_host.build_ext()
     import project_features_cuda as m
-    with pytest.raises(RuntimeError, match="encoded_2d_features must be a CUDA tensor"):
-        m.project_features_cuda(*_args())
+    assert m.IMPLEMENTATION == "compiled", "project_features_cuda did not pick up _project_features_ext.so"
+    return m
 
 
-def test_wrapper_signature_is_ten_positional_arguments():
+def test_wrapper_rejects_cpu_tensors_like_check_cuda(dropin):
+    for fn in (dropin.project_features_cuda, dropin.project_features_cuda_py):
+        with pytest.raises(RuntimeError, match="encoded_2d_features must be a CUDA tensor"):
+            fn(*_args())
+
+
+def test_wrapper_signature_is_ten_positional_arguments(dropin):
     import inspect
-
-    import project_features_cuda as m
-    params = list(inspect.signature(m.project_features_cuda).parameters)
-    assert params == ["encoded_2d_features", "occupancy_3D", "viewMatrixInv", "intrinsicParams", "opts",
-                      "mapping2dto3d_num", "projected_features", "pred_mode_t", "grid_origin", "voxel_size"]
+    assert list(inspect.signature(dropin.project_features_cuda_py).parameters) == TEN
+    # the compiled front is a pybind11 builtin: its generated docstring carries the signature
+    sig = dropin.project_features_cuda.__doc__.splitlines()[0]
+    assert re.findall(r"(\w+): ", sig) == TEN and sig.endswith("-> None")
+    # wrong arity raises TypeError on both, like any pybind11 / Python callable
+    for fn in (dropin.project_features_cuda, dropin.project_features_cuda_py):
+        with pytest.raises(TypeError):
+            fn(*_args()[:9])

@@ -20,10 +20,33 @@ def _no_heavy_path_by_default(monkeypatch):
     monkeypatch.setenv("VOXPROJ_HEAVY_T", "100000000")
 
 
-def _gpu_call(feats, occ, c2w, intr, opts, origin, vs, count_t, out_t):
+FRONT = {"name": "compiled"}
+
+
+@pytest.fixture(autouse=True, params=["compiled", "python"])
+def _front(request):
+    # every test runs through both fronts of the drop-in module: the compiled pybind11 wrapper
+    # (csrc/project_features_ext.cpp) and the ctypes one; both end in the same C-ABI call
     import project_features_cuda as m
+    if request.param == "compiled":
+        assert m.IMPLEMENTATION == "compiled", "_project_features_ext.so is not built: run __graft_entry__.build()"
+    FRONT["name"] = request.param
+    yield request.param
+
+
+def _drop_in():
+    import project_features_cuda as m
+    return m.project_features_cuda if FRONT["name"] == "compiled" else m.project_features_cuda_py
+
+
+def _last_ws():
+    import project_features_cuda as m
+    return m.last_workspace(torch.device(DEV), front=FRONT["name"])
+
+
+def _gpu_call(feats, occ, c2w, intr, opts, origin, vs, count_t, out_t):
     B = feats.shape[0]
-    m.project_features_cuda(
+    _drop_in()(
         torch.from_numpy(feats).to(DEV).contiguous(),
         torch.from_numpy(occ.astype(np.int64)).to(DEV).contiguous(),
         torch.from_numpy(np.ascontiguousarray(c2w, np.float32)).reshape(-1).to(DEV),
@@ -44,7 +67,7 @@ def _compare(oracle_mod, feats, occ, c2w, intr, opts, origin, vs, n_rows, expect
     count_t = torch.zeros(n_rows, dtype=torch.int32, device=DEV)
     out_t = torch.zeros(n_rows, C, dtype=torch.float32, device=DEV)
     _gpu_call(feats, occ, c2w, intr, opts, origin, vs, count_t, out_t)
-    ws = voxproj_host.get_workspace(torch.device(DEV))
+    ws = _last_ws()
     hits = voxproj_host.hit_image(ws, torch.device(DEV)).cpu().numpy()
     ctr = voxproj_host.counters(ws, torch.device(DEV))
     assert np.array_equal(hits, r["hits"]), f"first-hit IDs differ at {(hits != r['hits']).sum()} pixels"
@@ -187,8 +210,7 @@ def test_heavy_voxels_use_the_workgroup_path(oracle_mod, monkeypatch):
         feats = make_features_np(5, 32, 48, C, seed=31)[None]
         r, got, _ = _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size,
                              s.n_vox + 1, bitwise=False)
-        ws = voxproj_host.get_workspace(torch.device(DEV))
-        assert voxproj_host.counters(ws, torch.device(DEV))["n_heavy"] > 50
+        assert voxproj_host.counters(_last_ws(), torch.device(DEV))["n_heavy"] > 50
         _, got2, _ = _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size,
                               s.n_vox + 1, bitwise=False)
         assert got.tobytes() == got2.tobytes()
@@ -240,6 +262,43 @@ def test_pipelined_calls_of_varying_size(oracle_mod):
     assert out_t.cpu().numpy().tobytes() == out.tobytes()
 
 
+def test_occupancy_tables_follow_the_tensor_not_its_address(oracle_mod):
+    # the drop-in keeps the occupancy-derived tables between calls only for the very same, unmodified tensor:
+    # an in-place edit (version counter) and a new tensor at a recycled address must both rebuild them
+    import voxproj_host
+    s = make_scene(2000, 2, 40, 24, seed=61, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(2, 24, 40, 8, seed=61)[None]
+    n_rows = s.n_vox + 1
+    dev = torch.device(DEV)
+    fixed = (torch.from_numpy(s.c2w).reshape(-1).to(dev), torch.from_numpy(s.intr[None]).to(dev),
+             torch.from_numpy(s.opts()))
+    tail = (torch.tensor([False]), torch.from_numpy(s.grid_origin), s.voxel_size)
+    feats_t = torch.from_numpy(feats).to(dev)
+
+    def check(occ_t, occ_np):
+        count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        out_t = torch.zeros(n_rows, 8, device=dev)
+        _drop_in()(feats_t, occ_t, *fixed, count_t, out_t, *tail)
+        ref = oracle_mod.first_hit(occ_np[None].astype(np.int64), s.c2w.reshape(-1), s.intr[None], s.opts(),
+                                   s.grid_origin, s.voxel_size, 1, 2)
+        assert np.array_equal(voxproj_host.hit_image(_last_ws(), dev).cpu().numpy(), ref)
+        assert int(count_t.sum()) == int((ref > 0).sum())
+
+    occ_np = s.occ.copy()
+    occ_t = torch.from_numpy(occ_np[None].astype(np.int64)).to(dev)
+    check(occ_t, occ_np)
+    check(occ_t, occ_np)                                  # same tensor again: tables reused
+    zs = occ_np.shape[0]
+    occ_np[: zs // 2] = 0                                 # in-place edit of the same tensor
+    occ_t[:, : zs // 2] = 0
+    check(occ_t, occ_np)
+    del occ_t                                             # a different grid, most likely at the recycled address
+    occ_np2 = np.where(s.occ > 0, s.occ, 0).copy()
+    occ_np2[:, : occ_np2.shape[1] // 2] = 0
+    occ_t2 = torch.from_numpy(occ_np2[None].astype(np.int64)).to(dev)
+    check(occ_t2, occ_np2)
+
+
 def test_out_of_range_id_raises(oracle_mod):
     s = make_scene(2000, 1, 40, 24, seed=23, room=(5.0, 4.0, 2.4))
     feats = make_features_np(1, 24, 40, 8, seed=23)[None]
@@ -250,30 +309,30 @@ def test_out_of_range_id_raises(oracle_mod):
 
 
 def test_wrapper_checks_on_gpu():
-    import project_features_cuda as m
+    fn = _drop_in()
     B, V, H, W, C = 1, 1, 4, 4, 8
     a = [torch.zeros(B, V, H, W, C, device=DEV), torch.zeros(B, 2, 2, 2, dtype=torch.int64, device=DEV),
          torch.eye(4, device=DEV).reshape(-1), torch.ones(B, 4, device=DEV), torch.tensor([W, H, 0.01, 10.0, 0.5]),
          torch.zeros(3, dtype=torch.int32, device=DEV), torch.zeros(3, C, device=DEV), torch.tensor([False]),
          torch.zeros(3), 1.0]
-    assert m.project_features_cuda(*a) is None
+    assert fn(*a) is None
     for i, msg in [(1, "occupancy_3D must be int64"), (5, "mapping2dto3d_num must be int32")]:
         b = list(a)
         b[i] = b[i].float()
         with pytest.raises(RuntimeError, match=msg):
-            m.project_features_cuda(*b)
+            fn(*b)
     b = list(a)
     b[0] = a[0].permute(0, 1, 2, 4, 3)
     with pytest.raises(RuntimeError, match="encoded_2d_features must be contiguous"):
-        m.project_features_cuda(*b)
+        fn(*b)
     b = list(a)
     b[2] = a[2].reshape(4, 4)
     with pytest.raises(RuntimeError, match="viewMatrixInv must be 1D flattened"):
-        m.project_features_cuda(*b)
+        fn(*b)
     b = list(a)
     b[7] = torch.tensor([True])
     with pytest.raises(RuntimeError, match="pred_mode_t"):
-        m.project_features_cuda(*b)
+        fn(*b)
 
 
 def test_full_resolution_view_properties(oracle_mod):
@@ -287,13 +346,13 @@ def test_full_resolution_view_properties(oracle_mod):
     n_rows = s.n_vox + 1
     count_t = torch.zeros(n_rows, dtype=torch.int32, device=DEV)
     out_t = torch.zeros(n_rows, C, device=DEV)
-    import project_features_cuda as m
+    fn = _drop_in()
     occ_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(DEV)
     args = (feats, occ_t, torch.from_numpy(s.c2w[:1]).reshape(-1).to(DEV), torch.from_numpy(s.intr[None]).to(DEV),
             torch.from_numpy(s.opts()), count_t, out_t, torch.tensor([False]), torch.from_numpy(s.grid_origin),
             s.voxel_size)
-    m.project_features_cuda(*args)
-    ws = voxproj_host.get_workspace(torch.device(DEV))
+    fn(*args)
+    ws = _last_ws()
     hits = voxproj_host.hit_image(ws, torch.device(DEV))
     ref = oracle_mod.first_hit(s.occ[None].astype(np.int64), s.c2w[:1].reshape(-1), s.intr[None], s.opts(),
                                s.grid_origin, s.voxel_size, 1, 1)
@@ -318,7 +377,7 @@ def test_full_resolution_view_properties(oracle_mod):
             acc = acc + f2[j]
         assert torch.equal(acc, out_t[i]), i
     # idempotence of the accumulate contract: a second call doubles counts and (to rounding) sums
-    m.project_features_cuda(*args)
+    fn(*args)
     assert torch.equal(count_t.long(), 2 * torch.bincount(flat, minlength=n_rows) * (torch.arange(n_rows, device=DEV) > 0))
     assert ((out_t.double().sum(0) - 2 * tot_px).abs() <= 2e-6 * tot_abs).all()
 
