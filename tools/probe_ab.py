@@ -1,0 +1,58 @@
+"""A/B of two builds of libvoxproj.so on the SAME feature-pool allocation (its placement moves the gather's speed by
+several per cent, so builds cannot be compared across processes): python tools/probe_ab.py libA.so libB.so [...]
+Prints mean k_gather / k_first_hit time per launch, serial phases, R2 scene, 16 views per call."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-semantic-segmentation_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import voxproj_host  # noqa: E402
+from synthetic_scene import make_features_torch, make_scene  # noqa: E402
+
+libs = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
+pipeline = "--pipeline" in sys.argv
+dev = torch.device("cuda", 0)
+n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
+V, NCALL = 16, 8
+s = make_scene(n_vox, n_views, W, H, seed=0)
+occ = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+c2w = torch.from_numpy(s.c2w).to(dev)
+intr = torch.from_numpy(s.intr[None]).to(dev)
+opts = [float(v) for v in s.opts()]
+origin = [float(v) for v in s.grid_origin]
+vmis = [c2w[i * V:(i + 1) * V].reshape(-1).contiguous() for i in range(NCALL)]
+feats = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
+make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
+count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
+out = torch.zeros(n_vox + 1, C, dtype=torch.float32, device=dev)
+ref = None
+for rnd in range(3):
+    for path in libs:
+        voxproj_host._lib = None
+        voxproj_host.LIB_PATH = path
+        ws = voxproj_host.Workspace()
+        out.zero_(); count.zero_()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(3):
+            voxproj_host.profile_enable(rep > 0)
+            if rep == 1:
+                ev0.record()
+            for ci in range(NCALL):
+                voxproj_host.project_features_raw(feats, occ, vmis[ci], intr, opts, count, out, origin, s.voxel_size,
+                                                  workspace=ws, sync=False, reuse_accel=(ci + rep > 0 or None), pipeline=pipeline)
+            if pipeline:
+                voxproj_host.workspace_status(ws, dev)
+            torch.cuda.synchronize()
+        ev1.record(); torch.cuda.synchronize()
+        p = voxproj_host.profile_read()
+        voxproj_host.profile_enable(False)
+        chk = (int(count.sum().item()), float(out.double().sum().item()))
+        if ref is None:
+            ref = chk
+        print(f"round {rnd} {os.path.basename(path):24s} gather {p['gather_ms'] / max(p['gather_launches'], 1):.3f} ms/launch  "
+              f"march {p['first_hit_ms'] / max(p['first_hit_launches'], 1):.3f}  wall {ev0.elapsed_time(ev1) / (2 * NCALL):.3f} ms/call  "
+              f"same result: {chk == ref}", flush=True)
+        ws.release()
+        del ws
