@@ -54,7 +54,11 @@ def dropin():
     """The drop-in module with its compiled pybind11 front built (hipcc as host compiler, ~1 min the first time)."""
     import voxproj_host
     voxproj_host.build_ext()
+    import importlib
+
     import project_features_cuda as m
+    if m.IMPLEMENTATION != "compiled":      # imported before the extension existed
+        m = importlib.reload(m)
     assert m.IMPLEMENTATION == "compiled", "project_features_cuda did not pick up _project_features_ext.so"
     return m
 
