@@ -1,4 +1,4 @@
-// voxproj.hip -- MI355X (gfx950) 2D -> sparse-voxel feature projector: kernels + C-ABI.
+// voxproj.hip -- MI355X (gfx950) 2D -> sparse-voxel feature projector: C-ABI and launch plumbing (kernels in vp_*.h).
 //
 // Replaces the device path of the reference's project_features_cuda extension
 // (cuda_project_image_to_sparse_voxel/project_image_cuda_kernel.cu:24-92,140-334,374-459) with a
@@ -20,6 +20,13 @@
 //
 // No float atomics (deterministic sums), no MFMA (the path is gather/accumulate, HBM-bound).
 //
+// One translation unit: this file holds the host side (launch plumbing, C-ABI entry points) and includes
+//   vp_common.h  error text, timing spans, VP_FLAG_PIPELINE stream state, Params, workspace Layout
+//   vp_tables.h  arithmetic contract helpers, occupancy-derived tables, view table
+//   vp_march.h   phase 1 (k_first_hit)
+//   vp_gather.h  phase 2 (k_gather, k_gather_heavy)
+//   vp_aux.h     RGB projection, nearest-voxel map, streaming-read probe
+//
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include <hip/hip_runtime.h>
 
@@ -35,1192 +42,11 @@
 
 #include "voxproj.h"
 
-namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define VP_HIP(call)                                                                      \
-    do {                                                                                  \
-        hipError_t e_ = (call);                                                           \
-        if (e_ != hipSuccess)                                                             \
-            return fail(VP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
-                        __FILE__, __LINE__);                                              \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// optional per-kernel timing (HIP events on the launch stream)
-// ------------------------------------------------------------------------------------------------
-struct Profile {
-    std::mutex mu;
-    bool on = false;
-    std::vector<hipEvent_t> pool;    // event pairs
-    std::vector<int> kind;           // per pair: 0 prep, 1 first_hit, 2 gather, 3 heavy
-    size_t used = 0;                 // pairs in use
-    // returns the pair index, or -1
-    int next(int k)
-    {
-        if (used * 2 == pool.size()) {
-            hipEvent_t e0, e1;
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
-            pool.push_back(e0); pool.push_back(e1); kind.push_back(0);
-        }
-        kind[used] = k;
-        return (int)used++;
-    }
-} g_prof;
-
-// RAII-less helper: times [begin, end) of one kernel group on `stream` when profiling is on
-struct ProfSpan {
-    int idx = -1;
-    hipStream_t stream = nullptr;
-    void begin(int k, hipStream_t s)
-    {
-        std::lock_guard<std::mutex> g(g_prof.mu);
-        if (!g_prof.on) return;
-        idx = g_prof.next(k);
-        stream = s;
-        if (idx >= 0) (void)hipEventRecord(g_prof.pool[idx * 2], s);
-    }
-    void end()
-    {
-        if (idx < 0) return;
-        std::lock_guard<std::mutex> g(g_prof.mu);
-        (void)hipEventRecord(g_prof.pool[idx * 2 + 1], stream);
-        idx = -1;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// side stream + events for VP_FLAG_PIPELINE, one state per workspace pointer
-// ------------------------------------------------------------------------------------------------
-std::mutex g_pipe_mu;
-struct PipeState;
-std::vector<std::pair<void *, PipeState *>> g_pipes;
-struct PipeState {
-    hipStream_t side = nullptr;    // phase 1
-    hipStream_t side2 = nullptr;   // heavy-voxel kernel (its big workgroups are slow to place next to the gather;
-                                   // on a stream of its own it cannot hold up the next call's phase 1)
-    hipEvent_t fh_done[2] = {nullptr, nullptr};      // phase 1 of buffer set q finished (side stream)
-    hipEvent_t heavy_done[2] = {nullptr, nullptr};   // heavy-voxel kernel of set q finished (side stream)
-    hipEvent_t call_done[2] = {nullptr, nullptr};    // everything of the call that used set q finished (caller's stream)
-    hipEvent_t entry = nullptr;                      // caller's stream position at call entry
-    bool used[2] = {false, false};
-    long long calls = 0;
-    int last_q = 0;
-};
-// offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
-std::vector<std::pair<const void *, size_t>> g_last_hit;
-void remember_hit(const void *workspace, size_t off)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_last_hit)
-        if (kv.first == workspace) { kv.second = off; return; }
-    g_last_hit.emplace_back(workspace, off);
-}
-bool recall_hit(const void *workspace, size_t &off)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_last_hit)
-        if (kv.first == workspace) { off = kv.second; return true; }
-    return false;
-}
-
-PipeState *pipe_state(void *workspace, bool create)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_pipes)
-        if (kv.first == workspace) return kv.second;
-    if (!create) return nullptr;
-    PipeState *ps = new PipeState();
-    // (a high-priority side stream was measured: no effect on the pipelined step time, so plain streams)
-    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ps->side2, hipStreamNonBlocking) == hipSuccess;
-    for (int q = 0; q < 2 && ok; q++)
-        ok = hipEventCreateWithFlags(&ps->fh_done[q], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&ps->heavy_done[q], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&ps->call_done[q], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&ps->entry, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { delete ps; return nullptr; }
-    g_pipes.emplace_back(workspace, ps);
-    return ps;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Parameters shared by the kernels (by value, like the reference's RayCastParams, cudaUtil.h:74-96)
-// ------------------------------------------------------------------------------------------------
-struct Params {
-    int width, height;        // K.cu:403-404
-    float dmin, dmax, inc;    // K.cu:405-407
-    float ox, oy, oz, vs;     // K.cu:412-414
-    int dimz, dimy, dimx;     // K.cu:395-397
-    int B, V, C;
-    long long n_rows;
-};
-
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_WORDS = 64 };
-
-// per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
-struct ViewEntry {
-    float inv[9];   // row-major inverse of the upper-left 3x3 of c2w
-    float pos[3];   // camera position (c2w translation)
-    float ok;       // 1 if the inverse is usable, else 0 (forces whole-image boxes)
-    float pad[3];
-};
-
-// ------------------------------------------------------------------------------------------------
-// workspace layout (all offsets 256-byte aligned; occupancy-derived tables first so that their
-// position does not depend on the image shape -> VP_FLAG_REUSE_ACCEL)
-// ------------------------------------------------------------------------------------------------
-struct Layout {
-    size_t cell_of_id, mask64, near2, dist, dist_tmp;    // occupancy-derived tables (shared)
-    size_t status[2], cnt_call[2], heavy[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
-    size_t total;
-    int nbx, nby, nbz;
-    long long nblk;   // occupancy blocks (4x4x4 cells) per batch
-};
-
-inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
-
-// `capacity` = bytes of the caller's workspace (0 = compute the minimum).  The two per-call buffer sets sit
-// at offsets that depend only on (B, n_rows, grid dims, capacity), never on V/H/W, so that consecutive
-// pipelined calls of different V on one workspace cannot alias each other's buffers.
-Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int dimy, int dimx, size_t capacity = 0)
-{
-    Layout l;
-    size_t off = 0;
-    l.nbx = (dimx + 3) / 4; l.nby = (dimy + 3) / 4; l.nbz = (dimz + 3) / 4;
-    l.nblk = ((long long)l.nbx * l.nby * l.nbz + 15) & ~15ll;   // padded: per-batch tables stay 16-byte aligned
-    // status words of set 0 come first: vp_workspace_status/counters read the head of the workspace
-    l.status[0] = off;   off += align256(ST_WORDS * sizeof(int));
-    l.status[1] = off;   off += align256(ST_WORDS * sizeof(int));
-    l.cell_of_id = off;  off += align256(size_t(B) * size_t(n_rows) * sizeof(int));
-    l.mask64 = off;      off += align256(size_t(B) * l.nblk * sizeof(unsigned long long));
-    l.near2 = off;       off += align256(size_t(B) * l.nblk * 16);
-    l.dist = off;        off += align256(size_t(B) * l.nblk);
-    l.dist_tmp = off;    off += align256(size_t(B) * l.nblk);
-    for (int q = 0; q < 2; q++) {
-        l.cnt_call[q] = off; off += align256(size_t(n_rows) * sizeof(int));
-        l.heavy[q] = off;    off += align256(size_t(n_rows) * sizeof(int));
-    }
-    const size_t per_set = align256(size_t(B) * V * sizeof(ViewEntry)) + align256(size_t(B) * V * H * W * sizeof(int));
-    size_t half = per_set;
-    if (capacity > off + 2 * per_set) half = ((capacity - off) / 2) & ~size_t(255);
-    for (int q = 0; q < 2; q++) {
-        l.viewtab[q] = off + q * half;
-        l.hit[q] = l.viewtab[q] + align256(size_t(B) * V * sizeof(ViewEntry));
-    }
-    l.total = off + 2 * per_set;
-    return l;
-}
-
-// ------------------------------------------------------------------------------------------------
-// device helpers: the arithmetic contract of oracle/projector_oracle.c
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float round_half_away(float x)
-{   // C roundf; x - trunc(x) is exact in binary32
-    float t = truncf(x);
-    float d = fabsf(x - t);
-    return d >= 0.5f ? t + copysignf(1.0f, x) : t;
-}
-
-__device__ __forceinline__ int f2i_sat(float v)
-{   // cvt.rzi.s32.f32 / v_cvt_i32_f32 semantics: saturate, NaN -> 0
-    if (v != v) return 0;
-    v = fminf(fmaxf(v, -2147483648.0f), 2147483520.0f);
-    return (int)v;
-}
-
-// Closed-form advance of the ray parameter (used inside k_first_hit): J repetitions of t = fl(t + inc) without J
-// dependent additions.  While t stays inside one binade [T, 2T), T = 2^e > inc, every addition rounds to the same
-// grid of spacing u = ulp(T): fl(t + inc) = t + g with g = inc rounded to a multiple of u (unless inc lies exactly
-// half-way between two multiples, where round-to-even depends on t; that binade is stepped one addition at a
-// time).  g = fl(T + inc) - T.  For any m <= floor(((2T - u) - t) / g) each of the m exact sums t_i + inc stays
-// below 2T, so every step adds exactly g, and t + m*g (a multiple of u below 2T) is exactly representable: one
-// multiply and one add reproduce m additions.  m may be under-estimated (reciprocal scaled by 0.999999) -- the
-// remaining steps are then taken by real additions; the addition that crosses the binade edge is always a real
-// one.  All operations are IEEE binary32; tests compare 530k full-resolution rays with the oracle's plain loop.
-
-// ------------------------------------------------------------------------------------------------
-// occupancy-derived tables (built once per occupancy grid, see VP_FLAG_REUSE_ACCEL):
-//   cell_of_id[b][id]   linear cell index of voxel `id` (largest cell wins if an ID labels several)
-//   mask64[b][blk]      one bit per cell of each 4x4x4 block: (int)occ != 0   (bit = z%4*16+y%4*4+x%4)
-//   dist[b][blk]        Chebyshev distance, in blocks, to the nearest non-empty block (0 = non-empty,
-//                       capped at 255) -- a lower bound that lets the march leap over empty space
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_cells(const long long *__restrict__ occ, int *cell_of_id,
-                                                     unsigned long long *mask64,
-                                                     int dimz, int dimy, int dimx, int nby, int nbx,
-                                                     long long nblk, int B, long long n_rows)
-{
-    const long long cells_per_batch = (long long)dimz * dimy * dimx;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long total = cells_per_batch * B;
-    for (; i < total; i += stride) {
-        const int id = (int)occ[i];   // K.cu:70 long -> int
-        if (id == 0) continue;
-        const int b = (int)(i / cells_per_batch);
-        const int cell = (int)(i - (long long)b * cells_per_batch);
-        const int z = cell / (dimy * dimx), r = cell - z * (dimy * dimx), y = r / dimx, x = r - y * dimx;
-        const long long blk = ((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
-        const int bit = ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
-        atomicOr(&mask64[(long long)b * nblk + blk], 1ull << bit);
-        if (id > 0 && id < n_rows) atomicMax(&cell_of_id[(long long)b * n_rows + id], cell);
-    }
-}
-
-// Separable Chebyshev distance transform on the block grid: D = min_q max(|dx|,|dy|,|dz|) factors into
-// three 1-D passes because max distributes over min.  axis 0: along x from the masks; 1: y; 2: z.
-__global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__restrict__ mask64,
-                                                    const unsigned char *__restrict__ src,
-                                                    unsigned char *__restrict__ dst,
-                                                    int nbz, int nby, int nbx, long long nblk_padded, int B, int axis)
-{
-    const long long nreal = (long long)nbz * nby * nbx;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nreal * B) return;
-    const long long base = (i / nreal) * nblk_padded;     // per-batch tables are padded to 16 entries
-    const int blk = (int)(i % nreal);
-    const int z = blk / (nby * nbx), r = blk - z * (nby * nbx), y = r / nbx, x = r - y * nbx;
-    int best = 255;
-    if (axis == 0) {
-        for (int q = 0; q < nbx; q++)
-            if (mask64[base + ((long long)z * nby + y) * nbx + q] != 0ull) best = min(best, abs(x - q));
-    } else if (axis == 1) {
-        for (int q = 0; q < nby; q++)
-            best = min(best, max(abs(y - q), (int)src[base + ((long long)z * nby + q) * nbx + x]));
-    } else {
-        for (int q = 0; q < nbz; q++)
-            best = min(best, max(abs(z - q), (int)src[base + ((long long)q * nby + y) * nbx + x]));
-    }
-    dst[base + blk] = (unsigned char)best;
-}
-
-// Near field: for every cell of every block within one block of an occupied block, the Chebyshev distance in
-// CELLS to the nearest occupied cell, capped at 3 ("3 or more"), stored as two bit planes per 4x4x4 block
-// (nd = bit of .x | bit of .y << 1; nd == 0 <=> the cell is occupied).  One wavefront per block.
-__device__ __forceinline__ bool occ_bit(const unsigned long long *__restrict__ mask_b, int x, int y, int z,
-                                        int dimz, int dimy, int dimx, int nby, int nbx)
-{
-    if ((unsigned)x >= (unsigned)dimx || (unsigned)y >= (unsigned)dimy || (unsigned)z >= (unsigned)dimz) return false;
-    const unsigned long long m = mask_b[((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2)];
-    return (m >> (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))) & 1ull;
-}
-
-__global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__restrict__ mask64,
-                                                    const unsigned char *__restrict__ dist, ulonglong2 *near2,
-                                                    int dimz, int dimy, int dimx, int nbz, int nby, int nbx,
-                                                    long long nblk, int B)
-{
-    const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    const long long nreal = (long long)nbz * nby * nbx;
-    if (wid >= nreal * B) return;
-    const int b = (int)(wid / nreal);
-    const int blk = (int)(wid - (long long)b * nreal);
-    const unsigned long long *mask_b = mask64 + (long long)b * nblk;
-    int nd = 3;
-    if (dist[(long long)b * nblk + blk] <= 1) {
-        const int bz = blk / (nby * nbx), r = blk - bz * (nby * nbx), by = r / nbx, bx = r - by * nbx;
-        const int x = bx * 4 + (lane & 3), y = by * 4 + ((lane >> 2) & 3), z = bz * 4 + (lane >> 4);
-        if (occ_bit(mask_b, x, y, z, dimz, dimy, dimx, nby, nbx)) {
-            nd = 0;
-        } else {
-            for (int rad = 1; rad <= 2 && nd == 3; rad++)
-                for (int dz = -rad; dz <= rad && nd == 3; dz++)
-                    for (int dy = -rad; dy <= rad && nd == 3; dy++)
-                        for (int dx = -rad; dx <= rad; dx++) {
-                            if (max(abs(dx), max(abs(dy), abs(dz))) != rad) continue;
-                            if (occ_bit(mask_b, x + dx, y + dy, z + dz, dimz, dimy, dimx, nby, nbx)) { nd = rad; break; }
-                        }
-        }
-    }
-    const unsigned long long lo = __ballot(nd & 1), hi = __ballot(nd & 2);
-    if (lane == 0) near2[(long long)b * nblk + blk] = make_ulonglong2(lo, hi);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_viewtab: invert each view's 3x3 (double precision) for the phase-2 search boxes
-// ------------------------------------------------------------------------------------------------
-__global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *m = vmi + (long long)i * 16;
-    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], k = m[10];
-    double A = e * k - f * h, Bc = -(d * k - f * g), Cc = d * h - e * g;
-    double det = a * A + b * Bc + c * Cc;
-    ViewEntry ve;
-    double scale = fabs(a) + fabs(b) + fabs(c) + fabs(d) + fabs(e) + fabs(f) + fabs(g) + fabs(h) + fabs(k);
-    bool ok = (det == det) && fabs(det) > 1e-12 * scale * scale * scale && scale < 1e18;
-    double r = ok ? 1.0 / det : 0.0;
-    ve.inv[0] = (float)(A * r);  ve.inv[1] = (float)(-(b * k - c * h) * r); ve.inv[2] = (float)((b * f - c * e) * r);
-    ve.inv[3] = (float)(Bc * r); ve.inv[4] = (float)((a * k - c * g) * r);  ve.inv[5] = (float)(-(a * f - c * d) * r);
-    ve.inv[6] = (float)(Cc * r); ve.inv[7] = (float)(-(a * h - b * g) * r); ve.inv[8] = (float)((a * e - b * d) * r);
-    ve.pos[0] = m[3]; ve.pos[1] = m[7]; ve.pos[2] = m[11];
-    for (int j = 0; j < 9; j++) ok = ok && (fabsf(ve.inv[j]) < 1e18f);
-    for (int j = 0; j < 3; j++) ok = ok && (fabsf(ve.pos[j]) < 1e18f);
-    ve.ok = ok ? 1.0f : 0.0f;
-    ve.pad[0] = ve.pad[1] = ve.pad[2] = 0.0f;
-    tab[i] = ve;
-}
-
-// ------------------------------------------------------------------------------------------------
-// phase 1: first-hit ray-march.  One lane per pixel, 8x8 pixel tile per wavefront (coherent rays),
-// 16x16 per workgroup, blockIdx.z = b*V + v.
-//
-// ACCEL = false: the reference loop, one occupancy probe per step (K.cu:47-82), kept as the A/B arm.
-// ACCEL = true : the same sample sequence t_k (repeated fp32 addition, never t0 + k*inc), but
-//   * samples that provably cannot land in an occupied cell are not evaluated: from the block
-//     distance field, a sample in cell c with D = (lower bound on the Chebyshev distance, in cells,
-//     from c to the nearest occupied cell) allows skipping J steps with 1.5 + J*dcell <= D, where
-//     dcell bounds the per-step motion in cells (1% + fp slack, see DESIGN.md for the proof);
-//   * the cell index roundf((p - origin)/vs) is taken from the product with 1/vs when that product is
-//     farther than 2^-21*|q| from a rounding boundary (then both roundings agree), and from the IEEE
-//     division otherwise;
-//   * occupancy comes from a 64-bit block mask held in registers while the ray stays in a 4x4x4 block;
-//   * the (u,v) bounds test of K.cu:53-61 is evaluated, with the reference's exact operations, only
-//     for samples that found an occupied cell (it gates nothing else).
-// Every evaluated sample uses the reference's exact fp32 operations, so the first-hit ID is identical.
-// ------------------------------------------------------------------------------------------------
-// MODE 0: the reference loop (A/B arm, VP_FLAG_EXACT_MARCH); MODE 1: the leaping march.
-struct FirstHitArgs {
-    const long long *occ;
-    const float *vmi;
-    const float *intr;
-    const ulonglong2 *near2;
-    const unsigned char *dist;
-    int nby, nbx;
-    long long nblk;
-    int *hit;
-    int *cnt_call;
-    int *heavy_list;
-    int heavy_t;
-    int *status;
-};
-
-template <int MODE>
-__device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Params &p, int x, int y, int bv)
-{
-    constexpr bool ACCEL = MODE != 0;
-    const long long *__restrict__ occ = fa.occ;
-    const float *__restrict__ vmi = fa.vmi;
-    const float *__restrict__ intr = fa.intr;
-    const ulonglong2 *__restrict__ near2 = fa.near2;
-    const unsigned char *__restrict__ dist = fa.dist;
-    const int nby = fa.nby, nbx = fa.nbx;
-    const long long nblk = fa.nblk;
-    int *__restrict__ hit = fa.hit;
-    int *cnt_call = fa.cnt_call, *heavy_list = fa.heavy_list, *status = fa.status;
-    const int heavy_t = fa.heavy_t;
-    const int b = bv / p.V;
-    if (x >= p.width || y >= p.height) return;
-
-    const float *m = vmi + (long long)bv * 16;           // K.cu:178-179 (row-major float4x4)
-    const float fx = intr[b * 4 + 0], fy = intr[b * 4 + 1], mx = intr[b * 4 + 2], my = intr[b * 4 + 3];
-
-    // K.cu:182-184, cudaUtil.h:106-119
-    const float depth = 1.0f * (p.dmax - p.dmin) + p.dmin;
-    const float sx = ((float)(unsigned)x - mx) / fx;
-    const float sy = ((float)(unsigned)y - my) / fy;
-    float cx = depth * sx, cy = depth * sy, cz = depth;
-    float inv = 1.0f / sqrtf(cx * cx + cy * cy + cz * cz);   // cutil_math.h:1207-1211, :81-84
-    const float cdx = cx * inv, cdy = cy * inv, cdz = cz * inv;
-    // K.cu:185 float4x4 * float3 (w = 1), cuda_SimpleMatrixUtil.h:900-908
-    const float cpx = m[0] * 0.0f + m[1] * 0.0f + m[2] * 0.0f + m[3] * 1.0f;
-    const float cpy = m[4] * 0.0f + m[5] * 0.0f + m[6] * 0.0f + m[7] * 1.0f;
-    const float cpz = m[8] * 0.0f + m[9] * 0.0f + m[10] * 0.0f + m[11] * 1.0f;
-    // K.cu:186-187 float4x4 * float4(camDir, 0), cuda_SimpleMatrixUtil.h:888-896
-    float wx = m[0] * cdx + m[1] * cdy + m[2] * cdz + m[3] * 0.0f;
-    float wy = m[4] * cdx + m[5] * cdy + m[6] * cdz + m[7] * 0.0f;
-    float wz = m[8] * cdx + m[9] * cdy + m[10] * cdz + m[11] * 0.0f;
-    inv = 1.0f / sqrtf(wx * wx + wy * wy + wz * wz);
-    const float wdx = wx * inv, wdy = wy * inv, wdz = wz * inv;
-
-    // K.cu:31-82
-    const float d2r = 1.0f / cdz;
-    float t = d2r * p.dmin;
-    const float tEnd = d2r * p.dmax;
-    const long long cells = (long long)p.dimz * p.dimy * p.dimx;
-    const long long *occ_b = occ + (long long)b * cells;
-    const float fw = (float)p.width, fh = (float)p.height;
-    int id = 0;
-    // t += inc must make progress all the way to tEnd, or the loop (the reference's too, K.cu:47,81) never ends:
-    // ulp(t) <= ulp(tEnd), so it does iff adding inc changes tEnd.  Such a ray is reported, not marched.
-    if ((t < tEnd) && !(tEnd + p.inc > tEnd)) {
-        atomicOr(&status[ST_STUCK], 1);
-        t = tEnd;
-    }
-    if constexpr (!ACCEL) {
-        while (t < tEnd) {
-            const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
-            const int ix = f2i_sat(round_half_away((px - p.ox) / p.vs));
-            const int iy = f2i_sat(round_half_away((py - p.oy) / p.vs));
-            const int iz = f2i_sat(round_half_away((pz - p.oz) / p.vs));
-            const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
-            const float u = fx * (camx / camz) + mx;
-            const float v = fy * (camy / camz) + my;
-            const bool inb = (u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh);
-            if (inb && ix >= 0 && iy >= 0 && iz >= 0 && ix < p.dimx && iy < p.dimy && iz < p.dimz) {
-                id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
-                if (id != 0) break;
-            }
-            t += p.inc;
-        }
-    } else {
-        const ulonglong2 *near_b = near2 + (long long)b * nblk;
-        const unsigned char *dist_b = dist + (long long)b * nblk;
-        const float rvs = 1.0f / p.vs;
-        // upper bound of the per-step motion in cells (1% covers the rounding of t += inc and of rvs)
-        const float dcell = fabsf(p.inc * rvs) * fmaxf(fabsf(wdx), fmaxf(fabsf(wdy), fabsf(wdz))) * 1.01f + 1e-6f;
-        // leaping is allowed only where fp32 position error stays far below one cell and the step count
-        // is sane; otherwise every sample is evaluated (still exact, just slower)
-        const float span = (fabsf(cpx) + fabsf(cpy) + fabsf(cpz) + fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(tEnd)) * fabsf(rvs);
-        const bool leap_ok = (span < 131072.0f) & (fabsf(tEnd) < 1.0e5f * fabsf(p.inc)) & (dcell == dcell) & (dcell < 1.0e6f);
-        const float inv_dcell = leap_ok ? 0.999f / dcell : 0.0f;
-        // cell index from the product q = (p-o)*(1/vs) when |q - rint(q)| < thr: |q| <= span along the whole ray, so
-        // thr = 0.5 - 2^-21*span keeps q and the IEEE quotient on the same side of every rounding boundary
-        const float thr = leap_ok ? 0.5f - span * 0x1p-21f : -1.0f;
-        unsigned cur_blk = 0xffffffffu;
-        int cur_d = 0;
-        unsigned long long cur_lo = 0ull, cur_hi = 0ull;
-        int dbg_leap = 0, dbg_fine = 0;
-        // binade cache of the closed-form t advance (see advance_steps): valid while t < bT2
-        float bT2 = 0.0f, bTu = 0.0f, bg = 0.0f, brg = 0.0f;
-        while (t < tEnd) {
-            const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
-            const float ax = px - p.ox, ay = py - p.oy, az = pz - p.oz;
-            const float qx = ax * rvs, qy = ay * rvs, qz = az * rvs;
-            const float rx = rintf(qx), ry = rintf(qy), rz = rintf(qz);
-            const bool safe = (fabsf(qx - rx) < thr) & (fabsf(qy - ry) < thr) & (fabsf(qz - rz) < thr);
-            int ix = (int)rx, iy = (int)ry, iz = (int)rz;   // exact when safe (|q| < 2^17)
-            if (__builtin_expect(!safe, 0)) {
-                ix = f2i_sat(round_half_away(ax / p.vs));
-                iy = f2i_sat(round_half_away(ay / p.vs));
-                iz = f2i_sat(round_half_away(az / p.vs));
-            }
-            int D = 0;   // lower bound on the Chebyshev cell distance from (ix,iy,iz) to an occupied cell
-            const bool ing = ((unsigned)ix < (unsigned)p.dimx) & ((unsigned)iy < (unsigned)p.dimy) & ((unsigned)iz < (unsigned)p.dimz);
-            if (__builtin_expect(ing, 1)) {
-                const unsigned blk = ((unsigned)(iz >> 2) * (unsigned)nby + (unsigned)(iy >> 2)) * (unsigned)nbx + (unsigned)(ix >> 2);
-                if (blk != cur_blk) {
-                    cur_blk = blk;
-                    // both table reads go out together (the bit planes are only meaningful when cur_d <= 1)
-                    const ulonglong2 n2 = near_b[blk];
-                    cur_d = dist_b[blk];
-                    cur_lo = n2.x; cur_hi = n2.y;
-                }
-                const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
-                const int nd = (int)((cur_lo >> bit) & 1ull) | ((int)((cur_hi >> bit) & 1ull) << 1);
-                D = cur_d <= 1 ? nd : (cur_d - 1) * 4 + 1;
-                if (__builtin_expect((cur_d <= 1) & (nd == 0), 0)) {
-                    const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
-                    const float u = fx * (camx / camz) + mx;
-                    const float v = fy * (camy / camz) + my;
-                    if ((u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh)) {
-                        id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
-                        if (id != 0) break;
-                    }
-                }
-            } else if (leap_ok) {
-                const int lim = 1 << 29;
-                const int jx = min(max(ix, -lim), lim), jy = min(max(iy, -lim), lim), jz = min(max(iz, -lim), lim);
-                const int ex = jx < 0 ? -jx : (jx >= p.dimx ? jx - p.dimx + 1 : 0);
-                const int ey = jy < 0 ? -jy : (jy >= p.dimy ? jy - p.dimy + 1 : 0);
-                const int ez = jz < 0 ? -jz : (jz >= p.dimz ? jz - p.dimz + 1 : 0);
-                const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
-                const int kx = min(max(jx, 0), p.dimx - 1), ky = min(max(jy, 0), p.dimy - 1), kz = min(max(jz, 0), p.dimz - 1);
-                const int cb_ = ((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2);
-                const int dd = dist_b[cb_];
-                const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
-                D = max(dbox, din - dbox);
-            }
-            if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
-            // advance by 1 + J samples, J = floor((D - 1.5) / dcell) of them provably unable to reach an occupied
-            // cell; the running sum t is reproduced exactly by the closed form of advance_steps, with the binade
-            // constants cached across evaluations
-            int S = 1 + (D >= 2 ? (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f) : 0);
-            for (;;) {
-                if (t >= bT2) {
-                    const unsigned eb = __float_as_uint(t) & 0x7f800000u;
-                    const float T = __uint_as_float(eb);
-                    const float u = __uint_as_float(eb - (23u << 23));
-                    bT2 = __uint_as_float(eb + (1u << 23));
-                    bTu = bT2 - u;
-                    bg = (T + p.inc) - T;
-                    const float r = p.inc - bg;
-                    const bool fast = (t > 0.0f) & (eb >= (30u << 23)) & (eb < (0xfeu << 23)) & (p.inc < T) & (bg > 0.0f) & (fabsf(r) * 2.0f != u);
-                    brg = fast ? __builtin_amdgcn_rcpf(bg) * 0.999999f : 0.0f;   // under-estimate: m <= floor(A/g)
-                }
-                const int m = (int)fminf(fmaxf((bTu - t) * brg, 0.0f), (float)S);
-                t = t + (float)m * bg;
-                S -= m;
-                if (S <= 0) break;
-                t += p.inc;          // the addition that crosses the binade edge (or a binade stepped one by one)
-                S -= 1;
-                if (S <= 0 || !(t < tEnd)) break;
-            }
-        }
-        if (heavy_t < 0) {   // diagnostic build path (VOXPROJ_DEBUG_EVALS): per-ray evaluation counts instead of IDs
-            hit[((long long)bv * p.height + y) * p.width + x] = (dbg_leap << 16) | dbg_fine;
-            return;
-        }
-    }
-    if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
-        atomicOr(&status[ST_BADID], 1);
-        id = 0;
-    }
-    hit[((long long)bv * p.height + y) * p.width + x] = id;
-    // Per-call hit histogram, aggregated per wavefront: the lanes of an 8x8 tile share a handful of voxel IDs, so
-    // one lane per distinct ID adds the whole group (returning integer atomics on hot addresses were measured to
-    // slow a concurrently running gather 3-4x; this issues ~8x fewer of them).  The add that lifts a voxel's
-    // per-call count above heavy_t enlists it for the workgroup path.
-    {
-        // every lane leads at most one group (the group of its own ID), so the group sizes are collected first and
-        // ALL groups are added by one wave-level atomic instruction: one memory round trip instead of one per group
-        const int lane_ = threadIdx.x & 63;
-        int my_n = 0;
-        unsigned long long todo = __ballot(id != 0);
-        while (todo) {
-            const int l = __builtin_ctzll(todo);
-            const int cur = __builtin_amdgcn_readlane(id, l);
-            const unsigned long long m = __ballot(id == cur);
-            if (lane_ == l) my_n = __popcll(m);
-            todo &= ~m;
-        }
-        if (my_n > 0) {
-            const int old = atomicAdd(&cnt_call[id], my_n);
-            if (old <= heavy_t && old + my_n > heavy_t) heavy_list[atomicAdd(&status[ST_NHEAVY], 1)] = id;
-        }
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_first_hit(FirstHitArgs fa, Params p)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    first_hit_body<MODE>(fa, p, x, y, blockIdx.z);
-}
-
-// ------------------------------------------------------------------------------------------------
-// phase 2: one wavefront per voxel
-// ------------------------------------------------------------------------------------------------
-template <int K, int VEC>
-struct Acc {
-    float a[K * VEC];
-};
-
-// VEC == 8 selects the fp16 feature-map mode (8 halves = 16 B per lane per chunk; values are widened exactly and
-// summed in fp32 in the same order, so the outputs equal the fp32 path's on the same data).  Feature pointers are
-// carried as `const float *`; this advances one by `elems` ELEMENTS of the mode's input type.
-template <int VEC>
-__device__ __forceinline__ const float *feat_ptr(const float *base, long long elems)
-{
-    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + elems * (VEC == 8 ? 2 : 4));
-}
-
-// Scan the pixel box [x0,x1]x[y0,y1] of one view's ID image for pixels whose first hit is `id`, in
-// raster order, and add their feature rows (channels cb .. cb+64*K*VEC) to acc.  64 lanes cover a
-// tile of tw x (64/tw) pixels, tw = smallest power of two >= box width (capped at 64), so tiles
-// and the lanes inside a tile are visited in raster order.
-template <int K, int VEC, int U>
-__device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int *__restrict__ hv,
-                                         int W, int C, int id, int x0, int y0, int x1, int y1,
-                                         int cb, int lane, Acc<K, VEC> &acc, int &found)
-{
-    const int bw = x1 - x0 + 1;
-    const int lg = bw >= 64 ? 6 : (bw <= 1 ? 0 : 32 - __builtin_clz(bw - 1));
-    const int tw = 1 << lg, th = 64 >> lg;
-    const int lx = lane & (tw - 1), ly = lane >> lg;
-    for (int ty = y0; ty <= y1; ty += th) {
-        const int py = ty + ly;
-        for (int tx = x0; tx <= x1; tx += tw) {
-            const int px = tx + lx;
-            const bool inb = (px <= x1) && (py <= y1);
-            const int pix = py * W + px;
-            const int h = inb ? hv[pix] : 0;
-            unsigned long long m = __ballot(h == id);
-            found += __popcll(m);
-            while (m) {
-                int n = 0;
-                long long off[U];
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    off[j] = 0;
-                    if (m) {
-                        const int l = __builtin_ctzll(m);
-                        m &= m - 1;
-                        off[j] = (long long)__builtin_amdgcn_readlane(pix, l) * C + cb;
-                        n = j + 1;
-                    }
-                }
-                if constexpr (VEC == 8) {
-                    typedef _Float16 v8h_ __attribute__((ext_vector_type(8)));
-                    v8h_ r[U][K];
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if (j < n) {
-#pragma unroll
-                            for (int k = 0; k < K; k++) {
-                                const int ch = (k * 64 + lane) * 8;
-                                if (cb + ch < C)
-                                    r[j][k] = __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
-                                        reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2));
-                                else
-                                    r[j][k] = (v8h_)(_Float16)0;
-                            }
-                        }
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if (j < n) {
-#pragma unroll
-                            for (int k = 0; k < K; k++)
-#pragma unroll
-                                for (int e = 0; e < 8; e++) acc.a[k * 8 + e] += (float)r[j][k][e];
-                        }
-                } else if constexpr (VEC == 4) {
-                    float4 r[U][K];
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if (j < n) {
-#pragma unroll
-                            for (int k = 0; k < K; k++) {
-                                const int ch = (k * 64 + lane) * 4;
-                                // feature rows are read exactly once: non-temporal loads keep them out of L2/MALL
-                                // (+12 % gather bandwidth measured against plain loads)
-                                typedef float v4f_ __attribute__((ext_vector_type(4)));
-                                if (cb + ch < C) {
-                                    const v4f_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(fv + off[j] + ch));
-                                    r[j][k] = make_float4(t_.x, t_.y, t_.z, t_.w);
-                                } else {
-                                    r[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                                }
-                            }
-                        }
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if (j < n) {
-#pragma unroll
-                            for (int k = 0; k < K; k++) {
-                                acc.a[k * 4 + 0] += r[j][k].x;
-                                acc.a[k * 4 + 1] += r[j][k].y;
-                                acc.a[k * 4 + 2] += r[j][k].z;
-                                acc.a[k * 4 + 3] += r[j][k].w;
-                            }
-                        }
-                } else {
-                    float r[U][K];
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if (j < n) {
-#pragma unroll
-                            for (int k = 0; k < K; k++) {
-                                const int ch = k * 64 + lane;
-                                r[j][k] = (cb + ch < C) ? fv[off[j] + ch] : 0.f;
-                            }
-                        }
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if (j < n) {
-#pragma unroll
-                            for (int k = 0; k < K; k++) acc.a[k] += r[j][k];
-                        }
-                }
-            }
-        }
-    }
-}
-
-// Conservative pixel box of a voxel cube (centre c, half edge h) in view ve; returns false if empty.
-// Every ray sample has camera depth >= depthMin (t >= depthMin/camDir.z, K.cu:31-32), so the cube is
-// clipped against the plane z = zn = 0.98*depthMin before it is projected: vertices in front of the
-// plane are projected as they are, edges crossing it contribute their intersection point.
-__device__ __forceinline__ bool voxel_box(const ViewEntry &ve, float fx, float fy, float mx, float my,
-                                          float cxw, float cyw, float czw, float h, float zn, int W, int H,
-                                          int &x0, int &y0, int &x1, int &y1)
-{
-    x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
-    if (ve.ok == 0.0f) return true;
-    const float dx = cxw - ve.pos[0], dy = cyw - ve.pos[1], dz = czw - ve.pos[2];
-    const float camx = ve.inv[0] * dx + ve.inv[1] * dy + ve.inv[2] * dz;
-    const float camy = ve.inv[3] * dx + ve.inv[4] * dy + ve.inv[5] * dz;
-    const float camz = ve.inv[6] * dx + ve.inv[7] * dy + ve.inv[8] * dz;
-    const float ez = h * (fabsf(ve.inv[6]) + fabsf(ve.inv[7]) + fabsf(ve.inv[8]));
-    if (!(camz + ez > zn)) return false;                   // cube entirely nearer than any sample
-    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-    float qx[8], qy[8], qz[8];
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        const float a = (s & 1) ? h : -h, b = (s & 2) ? h : -h, c = (s & 4) ? h : -h;
-        qx[s] = camx + ve.inv[0] * a + ve.inv[1] * b + ve.inv[2] * c;
-        qy[s] = camy + ve.inv[3] * a + ve.inv[4] * b + ve.inv[5] * c;
-        qz[s] = camz + ve.inv[6] * a + ve.inv[7] * b + ve.inv[8] * c;
-        if (qz[s] >= zn) {
-            const float u = fx * (qx[s] / qz[s]) + mx, v = fy * (qy[s] / qz[s]) + my;
-            umin = fminf(umin, u); umax = fmaxf(umax, u);
-            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-        }
-    }
-    if (!(camz - ez >= zn)) {
-        // some vertices are behind the plane: add the 12 edges' crossings with z = zn
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-#pragma unroll
-            for (int ax = 0; ax < 3; ax++) {
-                const int o = s ^ (1 << ax);
-                if (o < s) continue;
-                const bool fs = qz[s] >= zn, fo = qz[o] >= zn;
-                if (fs == fo) continue;
-                const float tt = (zn - qz[s]) / (qz[o] - qz[s]);
-                const float ix = qx[s] + tt * (qx[o] - qx[s]), iy = qy[s] + tt * (qy[o] - qy[s]);
-                const float u = fx * (ix / zn) + mx, v = fy * (iy / zn) + my;
-                umin = fminf(umin, u); umax = fmaxf(umax, u);
-                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-            }
-        }
-        // crossing points are computed with cancellation: widen by 2 % of the box and 2 px
-        const float pu = 0.02f * (umax - umin) + 2.0f, pv = 0.02f * (vmax - vmin) + 2.0f;
-        umin -= pu; umax += pu; vmin -= pv; vmax += pv;
-    }
-    if (!(umin == umin) || !(umax == umax) || !(vmin == vmin) || !(vmax == vmax)) return true;
-    if (!(umin <= umax) || !(vmin <= vmax)) return true;   // nothing in front although the depth test passed
-    const float fW = (float)W, fH = (float)H;
-    if (umax < -2.0f || vmax < -2.0f || umin > fW + 1.0f || vmin > fH + 1.0f) return false;
-    x0 = max(0, (int)floorf(fmaxf(umin, 0.0f)) - 1);
-    y0 = max(0, (int)floorf(fmaxf(vmin, 0.0f)) - 1);
-    x1 = min(W - 1, (int)ceilf(fminf(umax, fW)) + 1);
-    y1 = min(H - 1, (int)ceilf(fminf(vmax, fH)) + 1);
-    return x0 <= x1 && y0 <= y1;
-}
-
-struct GatherArgs {
-    const float *feats;
-    const int *hit;
-    const ViewEntry *viewtab;
-    const float *intr;
-    const int *cell_of_id;
-    const int *cnt_call;
-    const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
-    const int *n_heavy;
-    int heavy_t;
-    int *count;
-    int *views_hit;          // nullable: += number of views of this call in which the voxel got >= 1 pixel
-    float *out;
-    int *status;
-};
-
-constexpr int GW = 16;   // wavefronts per k_gather_heavy workgroup
-
-template <int K, int VEC>
-__device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, int cb, int C, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if constexpr (VEC == 8) {
-            const int ch = (k * 64 + lane) * 8;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc.a[k * 8 + h * 4 + 0] = o.x; acc.a[k * 8 + h * 4 + 1] = o.y; acc.a[k * 8 + h * 4 + 2] = o.z; acc.a[k * 8 + h * 4 + 3] = o.w;
-            }
-        } else if constexpr (VEC == 4) {
-            const int ch = (k * 64 + lane) * 4;
-            const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-            acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
-        } else {
-            const int ch = k * 64 + lane;
-            acc.a[k] = (cb + ch < C) ? orow[ch] : 0.f;
-        }
-    }
-}
-
-template <int K, int VEC>
-__device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, int cb, int C, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if constexpr (VEC == 8) {
-            const int ch = (k * 64 + lane) * 8;
-            if (cb + ch < C) {
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    *reinterpret_cast<float4 *>(orow + ch + h * 4) = make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
-            }
-        } else if constexpr (VEC == 4) {
-            const int ch = (k * 64 + lane) * 4;
-            if (cb + ch < C)
-                *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
-        } else {
-            const int ch = k * 64 + lane;
-            if (cb + ch < C) orow[ch] = acc.a[k];
-        }
-    }
-}
-
-// world-space centre of voxel `id` in batch b; false if the grid of batch b does not hold the ID
-__device__ __forceinline__ bool voxel_centre(const GatherArgs &g, const Params &p, int b, int id,
-                                             float &cxw, float &cyw, float &czw)
-{
-    const int cell = g.cell_of_id[(long long)b * p.n_rows + id];
-    if (cell < 0) return false;
-    const int czi = cell / (p.dimy * p.dimx);
-    const int rem = cell - czi * (p.dimy * p.dimx);
-    const int cyi = rem / p.dimx, cxi = rem - cyi * p.dimx;
-    cxw = p.ox + (float)cxi * p.vs; cyw = p.oy + (float)cyi * p.vs; czw = p.oz + (float)czi * p.vs;
-    return true;
-}
-
-__device__ __forceinline__ float box_half_edge(const Params &p)
-{
-    return 0.5f * fabsf(p.vs) * 1.02f +
-           1e-6f * (fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(p.vs) * (p.dimx + p.dimy + p.dimz));
-}
-
-// camera depth below which no ray sample exists (t starts at depthMin/camDir.z); a non-positive or
-// non-finite depthMin degrades to a tiny positive plane (boxes grow, results stay exact)
-__device__ __forceinline__ float near_plane(const Params &p)
-{
-    const float zn = 0.98f * p.dmin;
-    return (zn > 1e-6f && zn < 1e30f) ? zn : 1e-6f;
-}
-
-// Normal role: one wavefront sums all pixels of one voxel, in (b, v, y, x) order, starting from the
-// row already in `out` -- bit-identical to the oracle's serial accumulation.
-template <int K, int VEC, int U>
-__device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Params &p, int id, int expected, int lane)
-{
-    const int W = p.width, H = p.height, C = p.C;
-    const long long HW = (long long)H * W;
-    const float hh = box_half_edge(p);
-    const float zn = near_plane(p);
-    constexpr int CB = 64 * K * VEC;
-    for (int cb = 0; cb < C; cb += CB) {
-        Acc<K, VEC> acc;
-        float *orow = g.out + (long long)id * C + cb;
-        acc_load<K, VEC>(acc, orow, cb, C, lane);
-        const Acc<K, VEC> acc0 = acc;
-        int found = 0, nviews = 0;
-        for (int b = 0; b < p.B && found < expected; b++) {
-            float cxw, cyw, czw;
-            if (!voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
-            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
-            for (int vbase = 0; vbase < p.V && found < expected; vbase += 64) {
-                const int v = vbase + lane;
-                int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-                bool ne = false;
-                if (v < p.V) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
-                unsigned long long vm = __ballot(ne);
-                while (vm && found < expected) {
-                    const int l = __builtin_ctzll(vm);
-                    vm &= vm - 1;
-                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
-                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
-                    const long long bv = (long long)b * p.V + vbase + l;
-                    const int before = found;
-                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
-                    nviews += found > before;
-                }
-            }
-        }
-        if (found != expected) {
-            // the search boxes missed pixels (an ID labelling several cells, a degenerate pose...):
-            // redo this voxel over whole images.  Correctness never depends on the boxes.
-            if (lane == 0 && cb == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-            acc = acc0;
-            found = 0;
-            nviews = 0;
-            for (long long bv = 0; bv < (long long)p.B * p.V; bv++) {
-                const int before = found;
-                scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
-                nviews += found > before;
-            }
-        }
-        acc_store<K, VEC>(acc, orow, cb, C, lane);
-        if (cb == 0 && lane == 0) {
-            g.count[id] += found;   // K.cu:77 (one add of the per-call total)
-            if (g.views_hit) g.views_hit[id] += nviews;
-        }
-    }
-}
-
-// Heavy role: the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
-// in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
-// each wavefront sums its range in raster order, and the partial rows are combined through LDS in
-// wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
-// the serial order in the last bits only, well inside the 1e-4 bar).
-template <int K, int VEC, int U>
-__device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id, int expected,
-                                   float (*part)[64 * K * VEC], int *part_found, bool whole_image)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
-    const int W = p.width, H = p.height, C = p.C;
-    const long long HW = (long long)H * W;
-    const float hh = box_half_edge(p);
-    const float zn = near_plane(p);
-    constexpr int CB = 64 * K * VEC;
-    constexpr int R = (CB + GW * 64 - 1) / (GW * 64);   // running-sum channels per thread
-    int found_total = 0, nviews = 0;
-    for (int cb = 0; cb < C; cb += CB) {
-        float run[R];
-        float *orow = g.out + (long long)id * C + cb;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int c = tid + r * GW * 64;
-            run[r] = (c < CB && cb + c < C) ? orow[c] : 0.f;
-        }
-        found_total = 0;
-        nviews = 0;
-        for (int b = 0; b < p.B && found_total < expected; b++) {
-            float cxw = 0.f, cyw = 0.f, czw = 0.f;
-            if (!whole_image && !voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
-            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
-            for (int vbase = 0; vbase < p.V && found_total < expected; vbase += 64) {
-                const int v = vbase + lane;
-                int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
-                bool ne = v < p.V;
-                if (ne && !whole_image) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
-                unsigned long long vm = __ballot(ne);   // identical in every wavefront of the workgroup
-                while (vm && found_total < expected) {
-                    const int l = __builtin_ctzll(vm);
-                    vm &= vm - 1;
-                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
-                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
-                    const long long bv = (long long)b * p.V + vbase + l;
-                    const int per = (by1 - by0 + GW) / GW;
-                    const int ry0 = by0 + w * per, ry1 = min(by1, ry0 + per - 1);
-                    Acc<K, VEC> acc;
-#pragma unroll
-                    for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
-                    int f = 0;
-                    if (ry0 <= ry1)
-                        scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, ry0, bx1, ry1, cb, lane, acc, f);
-#pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        if constexpr (VEC == 8) {
-#pragma unroll
-                            for (int h = 0; h < 2; h++)
-                                *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 8 + h * 4]) =
-                                    make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
-                        } else if constexpr (VEC == 4) {
-                            *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 4]) =
-                                make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
-                        } else {
-                            part[w][k * 64 + lane] = acc.a[k];
-                        }
-                    }
-                    if (lane == 0) part_found[w] = f;
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int c = tid + r * GW * 64;
-                        if (c < CB) {
-#pragma unroll
-                            for (int ww = 0; ww < GW; ww++) run[r] += part[ww][c];
-                        }
-                    }
-                    int fview = 0;
-#pragma unroll
-                    for (int ww = 0; ww < GW; ww++) fview += part_found[ww];
-                    found_total += fview;
-                    nviews += fview > 0;
-                    __syncthreads();
-                }
-            }
-        }
-        if (found_total != expected) return false;   // caller retries over whole images; nothing stored yet
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int c = tid + r * GW * 64;
-            if (c < CB && cb + c < C) orow[c] = run[r];
-        }
-    }
-    if (tid == 0) {
-        g.count[id] += found_total;
-        if (g.views_hit) g.views_hit[id] += nviews;
-    }
-    return true;
-}
-
-template <int K, int VEC, int U>
-__global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
-{
-    // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
-    // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
-    // march waves of the next call that share the SIMD in pipelined mode.
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x & 63;
-    const long long idl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
-    if (idl >= p.n_rows) return;
-    const int id = (int)idl;
-    const int expected = g.cnt_call[id];
-    if (expected == 0 || expected > g.heavy_t) return;
-    gather_voxel_wave<K, VEC, U>(g, p, id, expected, lane);
-}
-
-template <int K, int VEC, int U>
-__global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p)
-{
-    __shared__ __attribute__((aligned(16))) float part[GW][64 * K * VEC];
-    __shared__ int part_found[GW];
-    const int n_heavy = *g.n_heavy;
-    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const int id = g.heavy_list[h];
-        const int expected = g.cnt_call[id];
-        // first try the search boxes; on a pixel-count mismatch nothing was stored: redo over whole images
-        if (!gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, false)) {
-            if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-            gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// RGB path (BASELINE config 5): the reference's debug_project_colors.py:54-81 is a per-voxel Python loop --
-// voxel-driven, nearest pixel, NO occlusion test, numpy float64 arithmetic.  One lane per grid cell; an
-// occupied cell walks the views in order, so each voxel's float32 colour sum is accumulated in view order
-// exactly like aggregate_voxel_colors_onthefly.py:134-140 does (one contribution per view, no atomics).
-// Arithmetic contract: oracle_rgb_project in oracle/projector_oracle.c (separate multiplies and adds in
-// float64, IEEE divide, round-half-even).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ occ, int dimz, int dimy, int dimx,
-                                                        const float *__restrict__ c2w, const float *__restrict__ intr,
-                                                        int V, float ox, float oy, float oz, double vs,
-                                                        const unsigned char *__restrict__ img, int img_h, int img_w,
-                                                        float *color_sum, int *hit_count, int *first_view,
-                                                        long long n_rows, int view_base, int *status)
-{
-    const long long cells = (long long)dimz * dimy * dimx;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cells) return;
-    const int id = occ[i];
-    if (id <= 0) return;                                  // DPC:50 (occ > 0)
-    if (id >= n_rows) { atomicOr(&status[ST_BADID], 1); return; }
-    const int z = (int)(i / ((long long)dimy * dimx));
-    const int r = (int)(i - (long long)z * dimy * dimx);
-    const int y = r / dimx, x = r - y * dimx;
-    const double wx = (double)ox + vs * (double)x, wy = (double)oy + vs * (double)y, wz = (double)oz + vs * (double)z;   // DPC:60
-    float sr = color_sum[(long long)id * 3 + 0], sg = color_sum[(long long)id * 3 + 1], sb = color_sum[(long long)id * 3 + 2];
-    int hc = hit_count[id];
-    int fv = first_view ? first_view[id] : 0;
-    for (int v = 0; v < V; v++) {
-        const float *m = c2w + (long long)v * 16;
-        const double dx = wx - (double)m[3], dy = wy - (double)m[7], dz = wz - (double)m[11];                  // DPC:61-63
-        const double cx = (double)m[0] * dx + (double)m[4] * dy + (double)m[8] * dz;                            // R^T d
-        const double cy = (double)m[1] * dx + (double)m[5] * dy + (double)m[9] * dz;
-        const double cz = (double)m[2] * dx + (double)m[6] * dy + (double)m[10] * dz;
-        if (!(cz > 0.0)) continue;                                                                              // DPC:65
-        const double u = (double)intr[v * 4 + 0] * (cx / cz) + (double)intr[v * 4 + 2];                         // DPC:66-67
-        const double w = (double)intr[v * 4 + 1] * (cy / cz) + (double)intr[v * 4 + 3];
-        const double ur = rint(u), vr = rint(w);                                                                // DPC:68 (half to even)
-        if (!(ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h)) continue;                    // DPC:69
-        const unsigned char *px = img + (((long long)v * img_h + (int)vr) * img_w + (int)ur) * 3;
-        sr += (float)((double)px[0] / 255.0);                                                                   // DPC:70,75; AGGC:139
-        sg += (float)((double)px[1] / 255.0);
-        sb += (float)((double)px[2] / 255.0);
-        hc += 1;                                                                                                // AGGC:140
-        fv = min(fv, view_base + v);
-    }
-    color_sum[(long long)id * 3 + 0] = sr; color_sum[(long long)id * 3 + 1] = sg; color_sum[(long long)id * 3 + 2] = sb;
-    hit_count[id] = hc;
-    if (first_view) first_view[id] = fv;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stage-5 front end: nearest voxel of every Gaussian centre.  The reference builds an sklearn
-// KDTree over the voxel positions and queries k = 1 (voxel_to_gaussian/voxeltoGaussian_logits.py:87-105, same
-// code at voxeltoGaussian.py:84-93); distances there are float64 sums of squared float32 differences.  Here the
-// voxel positions are bucketed on a uniform grid (sorted by cell on the host side) and each lane searches
-// Chebyshev shells of cells around its query until the best squared distance (same float64 arithmetic) is
-// no larger than what any unexplored shell could offer: a point in a cell k shells away is at least (k-1)*h
-// away.  Exact; ties go to the lowest voxel index.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_nearest_voxel(const float *__restrict__ pts, const int *__restrict__ perm,
-                                                       const int *__restrict__ cell_start, double gx, double gy,
-                                                       double gz, double h, int nx, int ny, int nz,
-                                                       const float *__restrict__ q, long long M, long long *out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const double qx = (double)q[i * 3 + 0], qy = (double)q[i * 3 + 1], qz = (double)q[i * 3 + 2];
-    // query cell in (possibly out-of-range) grid coordinates
-    const double fx = floor((qx - gx) / h), fy = floor((qy - gy) / h), fz = floor((qz - gz) / h);
-    const double lim = 1.0e9;
-    const long long cx = (long long)fmin(fmax(fx, -lim), lim), cy = (long long)fmin(fmax(fy, -lim), lim),
-                    cz = (long long)fmin(fmax(fz, -lim), lim);
-    // first shell that can touch the grid
-    long long r0 = 0;
-    r0 = max(r0, max(-cx, cx - (nx - 1)));
-    r0 = max(r0, max(-cy, cy - (ny - 1)));
-    r0 = max(r0, max(-cz, cz - (nz - 1)));
-    const long long rmax = r0 + (long long)max(nx, max(ny, nz)) + 1;
-    double best = INFINITY;
-    long long best_idx = -1;
-    for (long long r = r0; r <= rmax; r++) {
-        const long long z0 = max(cz - r, 0ll), z1 = min(cz + r, (long long)nz - 1);
-        const long long y0 = max(cy - r, 0ll), y1 = min(cy + r, (long long)ny - 1);
-        const long long x0 = max(cx - r, 0ll), x1 = min(cx + r, (long long)nx - 1);
-        for (long long z = z0; z <= z1; z++)
-            for (long long y = y0; y <= y1; y++) {
-                const bool face = (llabs(z - cz) == r) || (llabs(y - cy) == r);
-                for (long long x = x0; x <= x1; x++) {
-                    if (!face && llabs(x - cx) != r) {          // interior of the shell: jump to the far side
-                        if (x < cx + r && cx + r <= x1) x = cx + r - 1;
-                        else break;
-                        continue;
-                    }
-                    const long long c = (z * ny + y) * nx + x;
-                    for (int k = cell_start[c]; k < cell_start[c + 1]; k++) {
-                        const double dx = qx - (double)pts[(long long)k * 3 + 0];
-                        const double dy = qy - (double)pts[(long long)k * 3 + 1];
-                        const double dz = qz - (double)pts[(long long)k * 3 + 2];
-                        const double d2 = dx * dx + dy * dy + dz * dz;
-                        const long long idx = perm[k];
-                        if (d2 < best || (d2 == best && idx < best_idx)) { best = d2; best_idx = idx; }
-                    }
-                }
-            }
-        // everything in shells > r is at least r*h away
-        const double bound = (double)r * h;
-        if (best_idx >= 0 && best <= bound * bound) break;
-    }
-    out[i] = best_idx;
-}
-
-// measurement aid (bench.py): plain streaming read of a buffer with 16-byte non-temporal loads, the on-box
-// ceiling the gather's achieved bandwidth is quoted against next to the nominal HBM peak
-__global__ __launch_bounds__(256) void k_stream_read(const float *__restrict__ src, long long n_vec4, float *sink)
-{
-    typedef float v4f_ __attribute__((ext_vector_type(4)));
-    const v4f_ *p = reinterpret_cast<const v4f_ *>(src);
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (; i + 3 * stride < n_vec4; i += 4 * stride) {
-        const v4f_ x0 = __builtin_nontemporal_load(p + i), x1 = __builtin_nontemporal_load(p + i + stride);
-        const v4f_ x2 = __builtin_nontemporal_load(p + i + 2 * stride), x3 = __builtin_nontemporal_load(p + i + 3 * stride);
-        a0 += x0.x + x0.y + x0.z + x0.w; a1 += x1.x + x1.y + x1.z + x1.w;
-        a2 += x2.x + x2.y + x2.z + x2.w; a3 += x3.x + x3.y + x3.z + x3.w;
-    }
-    for (; i < n_vec4; i += stride) {
-        const v4f_ x0 = __builtin_nontemporal_load(p + i);
-        a0 += x0.x + x0.y + x0.z + x0.w;
-    }
-    const float a = (a0 + a1) + (a2 + a3);
-    if (a == 1.2345678e30f) sink[0] = a;   // keeps the loads alive
-}
-
-}  // namespace
+#include "vp_common.h"
+#include "vp_tables.h"
+#include "vp_march.h"
+#include "vp_gather.h"
+#include "vp_aux.h"
 
 // ------------------------------------------------------------------------------------------------
 // host helpers

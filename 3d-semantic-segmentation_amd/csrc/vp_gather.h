@@ -1,0 +1,479 @@
+// vp_gather.h -- phase 2: one wavefront per voxel gathers and sums the feature rows of the pixels that first-hit it
+// (k_gather), a whole workgroup for voxels with very many pixels (k_gather_heavy).  Included by voxproj.hip only.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// phase 2: one wavefront per voxel
+// ------------------------------------------------------------------------------------------------
+template <int K, int VEC>
+struct Acc {
+    float a[K * VEC];
+};
+
+// VEC == 8 selects the fp16 feature-map mode (8 halves = 16 B per lane per chunk; values are widened exactly and
+// summed in fp32 in the same order, so the outputs equal the fp32 path's on the same data).  Feature pointers are
+// carried as `const float *`; this advances one by `elems` ELEMENTS of the mode's input type.
+template <int VEC>
+__device__ __forceinline__ const float *feat_ptr(const float *base, long long elems)
+{
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + elems * (VEC == 8 ? 2 : 4));
+}
+
+// Scan the pixel box [x0,x1]x[y0,y1] of one view's ID image for pixels whose first hit is `id`, in
+// raster order, and add their feature rows (channels cb .. cb+64*K*VEC) to acc.  64 lanes cover a
+// tile of tw x (64/tw) pixels, tw = smallest power of two >= box width (capped at 64), so tiles
+// and the lanes inside a tile are visited in raster order.
+template <int K, int VEC, int U>
+__device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int *__restrict__ hv,
+                                         int W, int C, int id, int x0, int y0, int x1, int y1,
+                                         int cb, int lane, Acc<K, VEC> &acc, int &found)
+{
+    const int bw = x1 - x0 + 1;
+    const int lg = bw >= 64 ? 6 : (bw <= 1 ? 0 : 32 - __builtin_clz(bw - 1));
+    const int tw = 1 << lg, th = 64 >> lg;
+    const int lx = lane & (tw - 1), ly = lane >> lg;
+    for (int ty = y0; ty <= y1; ty += th) {
+        const int py = ty + ly;
+        for (int tx = x0; tx <= x1; tx += tw) {
+            const int px = tx + lx;
+            const bool inb = (px <= x1) && (py <= y1);
+            const int pix = py * W + px;
+            const int h = inb ? hv[pix] : 0;
+            unsigned long long m = __ballot(h == id);
+            found += __popcll(m);
+            while (m) {
+                int n = 0;
+                long long off[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    off[j] = 0;
+                    if (m) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        off[j] = (long long)__builtin_amdgcn_readlane(pix, l) * C + cb;
+                        n = j + 1;
+                    }
+                }
+                if constexpr (VEC == 8) {
+                    typedef _Float16 v8h_ __attribute__((ext_vector_type(8)));
+                    v8h_ r[U][K];
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                const int ch = (k * 64 + lane) * 8;
+                                if (cb + ch < C)
+                                    r[j][k] = __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
+                                        reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2));
+                                else
+                                    r[j][k] = (v8h_)(_Float16)0;
+                            }
+                        }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++)
+#pragma unroll
+                                for (int e = 0; e < 8; e++) acc.a[k * 8 + e] += (float)r[j][k][e];
+                        }
+                } else if constexpr (VEC == 4) {
+                    float4 r[U][K];
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                const int ch = (k * 64 + lane) * 4;
+                                // feature rows are read exactly once: non-temporal loads keep them out of L2/MALL
+                                // (+12 % gather bandwidth measured against plain loads)
+                                typedef float v4f_ __attribute__((ext_vector_type(4)));
+                                if (cb + ch < C) {
+                                    const v4f_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(fv + off[j] + ch));
+                                    r[j][k] = make_float4(t_.x, t_.y, t_.z, t_.w);
+                                } else {
+                                    r[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                }
+                            }
+                        }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                acc.a[k * 4 + 0] += r[j][k].x;
+                                acc.a[k * 4 + 1] += r[j][k].y;
+                                acc.a[k * 4 + 2] += r[j][k].z;
+                                acc.a[k * 4 + 3] += r[j][k].w;
+                            }
+                        }
+                } else {
+                    float r[U][K];
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) {
+                                const int ch = k * 64 + lane;
+                                r[j][k] = (cb + ch < C) ? fv[off[j] + ch] : 0.f;
+                            }
+                        }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < K; k++) acc.a[k] += r[j][k];
+                        }
+                }
+            }
+        }
+    }
+}
+
+// Conservative pixel box of a voxel cube (centre c, half edge h) in view ve; returns false if empty.
+// Every ray sample has camera depth >= depthMin (t >= depthMin/camDir.z, K.cu:31-32), so the cube is
+// clipped against the plane z = zn = 0.98*depthMin before it is projected: vertices in front of the
+// plane are projected as they are, edges crossing it contribute their intersection point.
+__device__ __forceinline__ bool voxel_box(const ViewEntry &ve, float fx, float fy, float mx, float my,
+                                          float cxw, float cyw, float czw, float h, float zn, int W, int H,
+                                          int &x0, int &y0, int &x1, int &y1)
+{
+    x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
+    if (ve.ok == 0.0f) return true;
+    const float dx = cxw - ve.pos[0], dy = cyw - ve.pos[1], dz = czw - ve.pos[2];
+    const float camx = ve.inv[0] * dx + ve.inv[1] * dy + ve.inv[2] * dz;
+    const float camy = ve.inv[3] * dx + ve.inv[4] * dy + ve.inv[5] * dz;
+    const float camz = ve.inv[6] * dx + ve.inv[7] * dy + ve.inv[8] * dz;
+    const float ez = h * (fabsf(ve.inv[6]) + fabsf(ve.inv[7]) + fabsf(ve.inv[8]));
+    if (!(camz + ez > zn)) return false;                   // cube entirely nearer than any sample
+    float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+    float qx[8], qy[8], qz[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const float a = (s & 1) ? h : -h, b = (s & 2) ? h : -h, c = (s & 4) ? h : -h;
+        qx[s] = camx + ve.inv[0] * a + ve.inv[1] * b + ve.inv[2] * c;
+        qy[s] = camy + ve.inv[3] * a + ve.inv[4] * b + ve.inv[5] * c;
+        qz[s] = camz + ve.inv[6] * a + ve.inv[7] * b + ve.inv[8] * c;
+        if (qz[s] >= zn) {
+            const float u = fx * (qx[s] / qz[s]) + mx, v = fy * (qy[s] / qz[s]) + my;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        }
+    }
+    if (!(camz - ez >= zn)) {
+        // some vertices are behind the plane: add the 12 edges' crossings with z = zn
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+                const int o = s ^ (1 << ax);
+                if (o < s) continue;
+                const bool fs = qz[s] >= zn, fo = qz[o] >= zn;
+                if (fs == fo) continue;
+                const float tt = (zn - qz[s]) / (qz[o] - qz[s]);
+                const float ix = qx[s] + tt * (qx[o] - qx[s]), iy = qy[s] + tt * (qy[o] - qy[s]);
+                const float u = fx * (ix / zn) + mx, v = fy * (iy / zn) + my;
+                umin = fminf(umin, u); umax = fmaxf(umax, u);
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            }
+        }
+        // crossing points are computed with cancellation: widen by 2 % of the box and 2 px
+        const float pu = 0.02f * (umax - umin) + 2.0f, pv = 0.02f * (vmax - vmin) + 2.0f;
+        umin -= pu; umax += pu; vmin -= pv; vmax += pv;
+    }
+    if (!(umin == umin) || !(umax == umax) || !(vmin == vmin) || !(vmax == vmax)) return true;
+    if (!(umin <= umax) || !(vmin <= vmax)) return true;   // nothing in front although the depth test passed
+    const float fW = (float)W, fH = (float)H;
+    if (umax < -2.0f || vmax < -2.0f || umin > fW + 1.0f || vmin > fH + 1.0f) return false;
+    x0 = max(0, (int)floorf(fmaxf(umin, 0.0f)) - 1);
+    y0 = max(0, (int)floorf(fmaxf(vmin, 0.0f)) - 1);
+    x1 = min(W - 1, (int)ceilf(fminf(umax, fW)) + 1);
+    y1 = min(H - 1, (int)ceilf(fminf(vmax, fH)) + 1);
+    return x0 <= x1 && y0 <= y1;
+}
+
+struct GatherArgs {
+    const float *feats;
+    const int *hit;
+    const ViewEntry *viewtab;
+    const float *intr;
+    const int *cell_of_id;
+    const int *cnt_call;
+    const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
+    const int *n_heavy;
+    int heavy_t;
+    int *count;
+    int *views_hit;          // nullable: += number of views of this call in which the voxel got >= 1 pixel
+    float *out;
+    int *status;
+};
+
+constexpr int GW = 16;   // wavefronts per k_gather_heavy workgroup
+
+template <int K, int VEC>
+__device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, int cb, int C, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if constexpr (VEC == 8) {
+            const int ch = (k * 64 + lane) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc.a[k * 8 + h * 4 + 0] = o.x; acc.a[k * 8 + h * 4 + 1] = o.y; acc.a[k * 8 + h * 4 + 2] = o.z; acc.a[k * 8 + h * 4 + 3] = o.w;
+            }
+        } else if constexpr (VEC == 4) {
+            const int ch = (k * 64 + lane) * 4;
+            const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
+        } else {
+            const int ch = k * 64 + lane;
+            acc.a[k] = (cb + ch < C) ? orow[ch] : 0.f;
+        }
+    }
+}
+
+template <int K, int VEC>
+__device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, int cb, int C, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if constexpr (VEC == 8) {
+            const int ch = (k * 64 + lane) * 8;
+            if (cb + ch < C) {
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    *reinterpret_cast<float4 *>(orow + ch + h * 4) = make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+            }
+        } else if constexpr (VEC == 4) {
+            const int ch = (k * 64 + lane) * 4;
+            if (cb + ch < C)
+                *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+        } else {
+            const int ch = k * 64 + lane;
+            if (cb + ch < C) orow[ch] = acc.a[k];
+        }
+    }
+}
+
+// world-space centre of voxel `id` in batch b; false if the grid of batch b does not hold the ID
+__device__ __forceinline__ bool voxel_centre(const GatherArgs &g, const Params &p, int b, int id,
+                                             float &cxw, float &cyw, float &czw)
+{
+    const int cell = g.cell_of_id[(long long)b * p.n_rows + id];
+    if (cell < 0) return false;
+    const int czi = cell / (p.dimy * p.dimx);
+    const int rem = cell - czi * (p.dimy * p.dimx);
+    const int cyi = rem / p.dimx, cxi = rem - cyi * p.dimx;
+    cxw = p.ox + (float)cxi * p.vs; cyw = p.oy + (float)cyi * p.vs; czw = p.oz + (float)czi * p.vs;
+    return true;
+}
+
+__device__ __forceinline__ float box_half_edge(const Params &p)
+{
+    return 0.5f * fabsf(p.vs) * 1.02f +
+           1e-6f * (fabsf(p.ox) + fabsf(p.oy) + fabsf(p.oz) + fabsf(p.vs) * (p.dimx + p.dimy + p.dimz));
+}
+
+// camera depth below which no ray sample exists (t starts at depthMin/camDir.z); a non-positive or
+// non-finite depthMin degrades to a tiny positive plane (boxes grow, results stay exact)
+__device__ __forceinline__ float near_plane(const Params &p)
+{
+    const float zn = 0.98f * p.dmin;
+    return (zn > 1e-6f && zn < 1e30f) ? zn : 1e-6f;
+}
+
+// Normal role: one wavefront sums all pixels of one voxel, in (b, v, y, x) order, starting from the
+// row already in `out` -- bit-identical to the oracle's serial accumulation.
+template <int K, int VEC, int U>
+__device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Params &p, int id, int expected, int lane)
+{
+    const int W = p.width, H = p.height, C = p.C;
+    const long long HW = (long long)H * W;
+    const float hh = box_half_edge(p);
+    const float zn = near_plane(p);
+    constexpr int CB = 64 * K * VEC;
+    for (int cb = 0; cb < C; cb += CB) {
+        Acc<K, VEC> acc;
+        float *orow = g.out + (long long)id * C + cb;
+        acc_load<K, VEC>(acc, orow, cb, C, lane);
+        const Acc<K, VEC> acc0 = acc;
+        int found = 0, nviews = 0;
+        for (int b = 0; b < p.B && found < expected; b++) {
+            float cxw, cyw, czw;
+            if (!voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
+            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
+            for (int vbase = 0; vbase < p.V && found < expected; vbase += 64) {
+                const int v = vbase + lane;
+                int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+                bool ne = false;
+                if (v < p.V) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
+                unsigned long long vm = __ballot(ne);
+                while (vm && found < expected) {
+                    const int l = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
+                    const long long bv = (long long)b * p.V + vbase + l;
+                    const int before = found;
+                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
+                    nviews += found > before;
+                }
+            }
+        }
+        if (found != expected) {
+            // the search boxes missed pixels (an ID labelling several cells, a degenerate pose...):
+            // redo this voxel over whole images.  Correctness never depends on the boxes.
+            if (lane == 0 && cb == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+            acc = acc0;
+            found = 0;
+            nviews = 0;
+            for (long long bv = 0; bv < (long long)p.B * p.V; bv++) {
+                const int before = found;
+                scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, 0, 0, W - 1, H - 1, cb, lane, acc, found);
+                nviews += found > before;
+            }
+        }
+        acc_store<K, VEC>(acc, orow, cb, C, lane);
+        if (cb == 0 && lane == 0) {
+            g.count[id] += found;   // K.cu:77 (one add of the per-call total)
+            if (g.views_hit) g.views_hit[id] += nviews;
+        }
+    }
+}
+
+// Heavy role: the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
+// in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
+// each wavefront sums its range in raster order, and the partial rows are combined through LDS in
+// wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
+// the serial order in the last bits only, well inside the 1e-4 bar).
+template <int K, int VEC, int U>
+__device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id, int expected,
+                                   float (*part)[64 * K * VEC], int *part_found, bool whole_image)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+    const int W = p.width, H = p.height, C = p.C;
+    const long long HW = (long long)H * W;
+    const float hh = box_half_edge(p);
+    const float zn = near_plane(p);
+    constexpr int CB = 64 * K * VEC;
+    constexpr int R = (CB + GW * 64 - 1) / (GW * 64);   // running-sum channels per thread
+    int found_total = 0, nviews = 0;
+    for (int cb = 0; cb < C; cb += CB) {
+        float run[R];
+        float *orow = g.out + (long long)id * C + cb;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int c = tid + r * GW * 64;
+            run[r] = (c < CB && cb + c < C) ? orow[c] : 0.f;
+        }
+        found_total = 0;
+        nviews = 0;
+        for (int b = 0; b < p.B && found_total < expected; b++) {
+            float cxw = 0.f, cyw = 0.f, czw = 0.f;
+            if (!whole_image && !voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
+            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
+            for (int vbase = 0; vbase < p.V && found_total < expected; vbase += 64) {
+                const int v = vbase + lane;
+                int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
+                bool ne = v < p.V;
+                if (ne && !whole_image) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
+                unsigned long long vm = __ballot(ne);   // identical in every wavefront of the workgroup
+                while (vm && found_total < expected) {
+                    const int l = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
+                    const long long bv = (long long)b * p.V + vbase + l;
+                    const int per = (by1 - by0 + GW) / GW;
+                    const int ry0 = by0 + w * per, ry1 = min(by1, ry0 + per - 1);
+                    Acc<K, VEC> acc;
+#pragma unroll
+                    for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
+                    int f = 0;
+                    if (ry0 <= ry1)
+                        scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, ry0, bx1, ry1, cb, lane, acc, f);
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        if constexpr (VEC == 8) {
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+                                *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 8 + h * 4]) =
+                                    make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+                        } else if constexpr (VEC == 4) {
+                            *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 4]) =
+                                make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+                        } else {
+                            part[w][k * 64 + lane] = acc.a[k];
+                        }
+                    }
+                    if (lane == 0) part_found[w] = f;
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int c = tid + r * GW * 64;
+                        if (c < CB) {
+#pragma unroll
+                            for (int ww = 0; ww < GW; ww++) run[r] += part[ww][c];
+                        }
+                    }
+                    int fview = 0;
+#pragma unroll
+                    for (int ww = 0; ww < GW; ww++) fview += part_found[ww];
+                    found_total += fview;
+                    nviews += fview > 0;
+                    __syncthreads();
+                }
+            }
+        }
+        if (found_total != expected) return false;   // caller retries over whole images; nothing stored yet
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int c = tid + r * GW * 64;
+            if (c < CB && cb + c < C) orow[c] = run[r];
+        }
+    }
+    if (tid == 0) {
+        g.count[id] += found_total;
+        if (g.views_hit) g.views_hit[id] += nviews;
+    }
+    return true;
+}
+
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
+{
+    // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
+    // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
+    // march waves of the next call that share the SIMD in pipelined mode.
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const long long idl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
+    if (idl >= p.n_rows) return;
+    const int id = (int)idl;
+    const int expected = g.cnt_call[id];
+    if (expected == 0 || expected > g.heavy_t) return;
+    gather_voxel_wave<K, VEC, U>(g, p, id, expected, lane);
+}
+
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p)
+{
+    __shared__ __attribute__((aligned(16))) float part[GW][64 * K * VEC];
+    __shared__ int part_found[GW];
+    const int n_heavy = *g.n_heavy;
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const int id = g.heavy_list[h];
+        const int expected = g.cnt_call[id];
+        // first try the search boxes; on a pixel-count mismatch nothing was stored: redo over whole images
+        if (!gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, false)) {
+            if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+            gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
+        }
+    }
+}
+
+}  // namespace

@@ -1,0 +1,160 @@
+// vp_tables.h -- the arithmetic contract shared with oracle/projector_oracle.c (rounding, float->int), and the
+// tables derived once per occupancy grid (ID -> cell, 4x4x4 block masks, block distance field, near-field cell
+// distances) plus the per-call view table.  Included by voxproj.hip only.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device helpers: the arithmetic contract of oracle/projector_oracle.c
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float round_half_away(float x)
+{   // C roundf; x - trunc(x) is exact in binary32
+    float t = truncf(x);
+    float d = fabsf(x - t);
+    return d >= 0.5f ? t + copysignf(1.0f, x) : t;
+}
+
+__device__ __forceinline__ int f2i_sat(float v)
+{   // cvt.rzi.s32.f32 / v_cvt_i32_f32 semantics: saturate, NaN -> 0
+    if (v != v) return 0;
+    v = fminf(fmaxf(v, -2147483648.0f), 2147483520.0f);
+    return (int)v;
+}
+
+// Closed-form advance of the ray parameter (used inside k_first_hit): J repetitions of t = fl(t + inc) without J
+// dependent additions.  While t stays inside one binade [T, 2T), T = 2^e > inc, every addition rounds to the same
+// grid of spacing u = ulp(T): fl(t + inc) = t + g with g = inc rounded to a multiple of u (unless inc lies exactly
+// half-way between two multiples, where round-to-even depends on t; that binade is stepped one addition at a
+// time).  g = fl(T + inc) - T.  For any m <= floor(((2T - u) - t) / g) each of the m exact sums t_i + inc stays
+// below 2T, so every step adds exactly g, and t + m*g (a multiple of u below 2T) is exactly representable: one
+// multiply and one add reproduce m additions.  m may be under-estimated (reciprocal scaled by 0.999999) -- the
+// remaining steps are then taken by real additions; the addition that crosses the binade edge is always a real
+// one.  All operations are IEEE binary32; tests compare 530k full-resolution rays with the oracle's plain loop.
+
+// ------------------------------------------------------------------------------------------------
+// occupancy-derived tables (built once per occupancy grid, see VP_FLAG_REUSE_ACCEL):
+//   cell_of_id[b][id]   linear cell index of voxel `id` (largest cell wins if an ID labels several)
+//   mask64[b][blk]      one bit per cell of each 4x4x4 block: (int)occ != 0   (bit = z%4*16+y%4*4+x%4)
+//   dist[b][blk]        Chebyshev distance, in blocks, to the nearest non-empty block (0 = non-empty,
+//                       capped at 255) -- a lower bound that lets the march leap over empty space
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_cells(const long long *__restrict__ occ, int *cell_of_id,
+                                                     unsigned long long *mask64,
+                                                     int dimz, int dimy, int dimx, int nby, int nbx,
+                                                     long long nblk, int B, long long n_rows)
+{
+    const long long cells_per_batch = (long long)dimz * dimy * dimx;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long total = cells_per_batch * B;
+    for (; i < total; i += stride) {
+        const int id = (int)occ[i];   // K.cu:70 long -> int
+        if (id == 0) continue;
+        const int b = (int)(i / cells_per_batch);
+        const int cell = (int)(i - (long long)b * cells_per_batch);
+        const int z = cell / (dimy * dimx), r = cell - z * (dimy * dimx), y = r / dimx, x = r - y * dimx;
+        const long long blk = ((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2);
+        const int bit = ((z & 3) << 4) | ((y & 3) << 2) | (x & 3);
+        atomicOr(&mask64[(long long)b * nblk + blk], 1ull << bit);
+        if (id > 0 && id < n_rows) atomicMax(&cell_of_id[(long long)b * n_rows + id], cell);
+    }
+}
+
+// Separable Chebyshev distance transform on the block grid: D = min_q max(|dx|,|dy|,|dz|) factors into
+// three 1-D passes because max distributes over min.  axis 0: along x from the masks; 1: y; 2: z.
+__global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__restrict__ mask64,
+                                                    const unsigned char *__restrict__ src,
+                                                    unsigned char *__restrict__ dst,
+                                                    int nbz, int nby, int nbx, long long nblk_padded, int B, int axis)
+{
+    const long long nreal = (long long)nbz * nby * nbx;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nreal * B) return;
+    const long long base = (i / nreal) * nblk_padded;     // per-batch tables are padded to 16 entries
+    const int blk = (int)(i % nreal);
+    const int z = blk / (nby * nbx), r = blk - z * (nby * nbx), y = r / nbx, x = r - y * nbx;
+    int best = 255;
+    if (axis == 0) {
+        for (int q = 0; q < nbx; q++)
+            if (mask64[base + ((long long)z * nby + y) * nbx + q] != 0ull) best = min(best, abs(x - q));
+    } else if (axis == 1) {
+        for (int q = 0; q < nby; q++)
+            best = min(best, max(abs(y - q), (int)src[base + ((long long)z * nby + q) * nbx + x]));
+    } else {
+        for (int q = 0; q < nbz; q++)
+            best = min(best, max(abs(z - q), (int)src[base + ((long long)q * nby + y) * nbx + x]));
+    }
+    dst[base + blk] = (unsigned char)best;
+}
+
+// Near field: for every cell of every block within one block of an occupied block, the Chebyshev distance in
+// CELLS to the nearest occupied cell, capped at 3 ("3 or more"), stored as two bit planes per 4x4x4 block
+// (nd = bit of .x | bit of .y << 1; nd == 0 <=> the cell is occupied).  One wavefront per block.
+__device__ __forceinline__ bool occ_bit(const unsigned long long *__restrict__ mask_b, int x, int y, int z,
+                                        int dimz, int dimy, int dimx, int nby, int nbx)
+{
+    if ((unsigned)x >= (unsigned)dimx || (unsigned)y >= (unsigned)dimy || (unsigned)z >= (unsigned)dimz) return false;
+    const unsigned long long m = mask_b[((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2)];
+    return (m >> (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))) & 1ull;
+}
+
+__global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__restrict__ mask64,
+                                                    const unsigned char *__restrict__ dist, ulonglong2 *near2,
+                                                    int dimz, int dimy, int dimx, int nbz, int nby, int nbx,
+                                                    long long nblk, int B)
+{
+    const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long long nreal = (long long)nbz * nby * nbx;
+    if (wid >= nreal * B) return;
+    const int b = (int)(wid / nreal);
+    const int blk = (int)(wid - (long long)b * nreal);
+    const unsigned long long *mask_b = mask64 + (long long)b * nblk;
+    int nd = 3;
+    if (dist[(long long)b * nblk + blk] <= 1) {
+        const int bz = blk / (nby * nbx), r = blk - bz * (nby * nbx), by = r / nbx, bx = r - by * nbx;
+        const int x = bx * 4 + (lane & 3), y = by * 4 + ((lane >> 2) & 3), z = bz * 4 + (lane >> 4);
+        if (occ_bit(mask_b, x, y, z, dimz, dimy, dimx, nby, nbx)) {
+            nd = 0;
+        } else {
+            for (int rad = 1; rad <= 2 && nd == 3; rad++)
+                for (int dz = -rad; dz <= rad && nd == 3; dz++)
+                    for (int dy = -rad; dy <= rad && nd == 3; dy++)
+                        for (int dx = -rad; dx <= rad; dx++) {
+                            if (max(abs(dx), max(abs(dy), abs(dz))) != rad) continue;
+                            if (occ_bit(mask_b, x + dx, y + dy, z + dz, dimz, dimy, dimx, nby, nbx)) { nd = rad; break; }
+                        }
+        }
+    }
+    const unsigned long long lo = __ballot(nd & 1), hi = __ballot(nd & 2);
+    if (lane == 0) near2[(long long)b * nblk + blk] = make_ulonglong2(lo, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_viewtab: invert each view's 3x3 (double precision) for the phase-2 search boxes
+// ------------------------------------------------------------------------------------------------
+__global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *m = vmi + (long long)i * 16;
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], k = m[10];
+    double A = e * k - f * h, Bc = -(d * k - f * g), Cc = d * h - e * g;
+    double det = a * A + b * Bc + c * Cc;
+    ViewEntry ve;
+    double scale = fabs(a) + fabs(b) + fabs(c) + fabs(d) + fabs(e) + fabs(f) + fabs(g) + fabs(h) + fabs(k);
+    bool ok = (det == det) && fabs(det) > 1e-12 * scale * scale * scale && scale < 1e18;
+    double r = ok ? 1.0 / det : 0.0;
+    ve.inv[0] = (float)(A * r);  ve.inv[1] = (float)(-(b * k - c * h) * r); ve.inv[2] = (float)((b * f - c * e) * r);
+    ve.inv[3] = (float)(Bc * r); ve.inv[4] = (float)((a * k - c * g) * r);  ve.inv[5] = (float)(-(a * f - c * d) * r);
+    ve.inv[6] = (float)(Cc * r); ve.inv[7] = (float)(-(a * h - b * g) * r); ve.inv[8] = (float)((a * e - b * d) * r);
+    ve.pos[0] = m[3]; ve.pos[1] = m[7]; ve.pos[2] = m[11];
+    for (int j = 0; j < 9; j++) ok = ok && (fabsf(ve.inv[j]) < 1e18f);
+    for (int j = 0; j < 3; j++) ok = ok && (fabsf(ve.pos[j]) < 1e18f);
+    ve.ok = ok ? 1.0f : 0.0f;
+    ve.pad[0] = ve.pad[1] = ve.pad[2] = 0.0f;
+    tab[i] = ve;
+}
+
+}  // namespace

@@ -36,9 +36,10 @@ class VoxprojError(RuntimeError):
 
 def build(force=False):
     """Compile libvoxproj.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    src = os.path.join(_HERE, "csrc", "voxproj.hip")
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "voxproj.h")
-    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f == "voxproj.hip" or (f.startswith("vp_") and f.endswith(".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "voxproj.h"))
+    newest = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"] + (["-B"] if force else []))
     return LIB_PATH
