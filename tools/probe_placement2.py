@@ -21,6 +21,7 @@ opts = [float(v) for v in s.opts()]
 origin = [float(v) for v in s.grid_origin]
 vmis = [c2w[i * V:(i + 1) * V].reshape(-1).contiguous() for i in range(NCALL)]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+pipeline = "--pipeline" in sys.argv
 
 feats = out = count = ws = None
 for rnd in range(6):
@@ -45,10 +46,13 @@ for rnd in range(6):
         voxproj_host.profile_enable(rep > 0)
         for ci in range(NCALL):
             voxproj_host.project_features_raw(feats, occ, vmis[ci], intr, opts, count, out, origin, s.voxel_size,
-                                              workspace=ws, sync=False, reuse_accel=(ci > 0 or None))
+                                              workspace=ws, sync=False, reuse_accel=(ci > 0 or None), pipeline=pipeline)
+        if pipeline:
+            voxproj_host.workspace_status(ws, dev)
         torch.cuda.synchronize()
         if rep > 0:
             p = voxproj_host.profile_read()
             res.append(p["gather_ms"] / max(p["gather_launches"], 1))
         voxproj_host.profile_enable(False)
-    print(f"realloc {which} round {rnd}: gather ms/launch per repeat:", " ".join(f"{r:.3f}" for r in res), flush=True)
+    print(f"realloc {which} round {rnd}: feats@{feats.data_ptr():#x} out@{out.data_ptr():#x} count@{count.data_ptr():#x} "
+          f"ws@{ws.ptr():#x}  gather ms/launch per repeat:", " ".join(f"{r:.3f}" for r in res), flush=True)
