@@ -15,8 +15,35 @@ def short(name):
     return name[:60]
 
 
+def from_rocpd(db):
+    """rocprofv3's default output on ROCm 7.2 is a rocpd SQLite database: same two summaries from its views."""
+    import sqlite3
+    con = sqlite3.connect(db)
+    views = {r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")}
+    if "top_kernels" in views:
+        rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        if rows:
+            print("-- kernel stats (rocprofv3 --kernel-trace --stats, rocpd top_kernels): name, calls, total_ms, avg_us, pct")
+            for name, calls, tot, avg, pct in rows:
+                if "k_" in name or float(pct) >= 1.0:
+                    print(f"{short(name):20s} {int(calls):6d} {float(tot)/1e3:10.3f} {float(avg):10.1f} {float(pct):6.2f}")
+    if "counters_collection" in views:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for name, counter, value in con.execute("select kernel_name, counter_name, value from counters_collection"):
+            agg[short(name)][counter].append(float(value))
+        if agg:
+            print("-- counters (rocprofv3 --pmc, rocpd counters_collection): kernel, counter, launches, mean per launch")
+            for k, cs in agg.items():
+                if not k.startswith("k_"):
+                    continue
+                for c, v in cs.items():
+                    print(f"{k:20s} {c:22s} {len(v):6d} {sum(v)/len(v):16.1f}")
+
+
 for d in sys.argv[1:]:
     print(f"== {d}")
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        from_rocpd(f)
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         print("-- kernel stats (rocprofv3 --kernel-trace --stats): name, calls, total_ms, avg_us, pct")
         for r in csv.DictReader(open(f)):
