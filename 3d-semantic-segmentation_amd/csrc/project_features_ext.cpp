@@ -132,7 +132,10 @@ void project_features_cuda(at::Tensor encoded_2d_features, at::Tensor occupancy_
                        st.occ_shape == occupancy_3D.sizes().vec() && st.n_rows == n_rows &&
                        !env_on("VOXPROJ_NO_ACCEL_CACHE");
     // A/B arm of the leaping march: evaluate every ray sample (same results)
-    const int flags = VP_FLAG_SYNC | (reuse ? VP_FLAG_REUSE_ACCEL : 0) | (env_on("VOXPROJ_EXACT_MARCH") ? VP_FLAG_EXACT_MARCH : 0);
+    // not the same tensor: let the library compare the grid with the copy its tables were built from (the reference's
+    // caller makes a new, equal `.long()` tensor for every call, debug_project_features.py:143)
+    const int flags = VP_FLAG_SYNC | (reuse ? VP_FLAG_REUSE_ACCEL : (env_on("VOXPROJ_NO_ACCEL_CACHE") ? 0 : VP_FLAG_VERIFY_ACCEL)) |
+                      (env_on("VOXPROJ_EXACT_MARCH") ? VP_FLAG_EXACT_MARCH : 0);
 
     // blocks until the device is done, GIL held, like the reference (kernel.cu:454-457)
     const int rc = vp_project_features(encoded_2d_features.data_ptr<float>(), occupancy_3D.data_ptr<int64_t>(),

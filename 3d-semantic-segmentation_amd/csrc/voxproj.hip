@@ -140,7 +140,33 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     int *hit = (int *)(ws + l.hit[q]);
     remember_hit(workspace, l.hit[q]);
 
-    if (!(flags & VP_FLAG_REUSE_ACCEL)) {
+    // Occupancy-derived tables: rebuilt unless the caller vouches for them (VP_FLAG_REUSE_ACCEL) or asks for a
+    // check (VP_FLAG_VERIFY_ACCEL, blocking calls only): then the grid is compared with the copy the tables were
+    // built from, and they are rebuilt only if a cell changed.
+    const long long cells = (long long)dimz * dimy * dimx;
+    int *occ_copy = (int *)(ws + l.occ_copy);
+    AccelRecord rec = accel_get(workspace);
+    const bool rec_matches = rec.B == B && rec.dimz == dimz && rec.dimy == dimy && rec.dimx == dimx && rec.n_rows == n_rows;
+    const bool verify = (flags & VP_FLAG_VERIFY_ACCEL) && !pipe && !(flags & VP_FLAG_REUSE_ACCEL);
+    const int cmp_blocks = (int)((cells * B + 255) / 256 > 8192 ? 8192 : (cells * B + 255) / 256);
+    bool rebuild = !(flags & VP_FLAG_REUSE_ACCEL);
+    if (verify && rec_matches && rec.copy_valid) {
+        int differs = 1;
+        VP_HIP(hipMemsetAsync(status + ST_OCCDIFF, 0, sizeof(int), s0));
+        hipLaunchKernelGGL(k_occ_compare_copy, dim3(cmp_blocks), dim3(256), 0, s0, (const long long *)occ, occ_copy, cells * B, status + ST_OCCDIFF);
+        VP_HIP(hipMemcpyAsync(&differs, status + ST_OCCDIFF, sizeof(int), hipMemcpyDeviceToHost, s0));
+        VP_HIP(hipStreamSynchronize(s0));
+        rebuild = differs != 0;      // the copy is already up to date either way
+    } else if (rebuild) {
+        if (verify) {
+            // first checked call on this workspace / new shape: take the copy now
+            hipLaunchKernelGGL(k_occ_compare_copy, dim3(cmp_blocks), dim3(256), 0, s0, (const long long *)occ, occ_copy, cells * B, status + ST_OCCDIFF);
+            rec.copy_valid = true;
+        } else {
+            rec.copy_valid = false;  // tables rebuilt without refreshing the copy
+        }
+    }
+    if (rebuild) {
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
         if (pipe) {
             VP_HIP(hipStreamSynchronize(ps->side));
@@ -150,7 +176,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         ProfSpan sp; sp.begin(0, s0);
         VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), s0));
         VP_HIP(hipMemsetAsync(mask64, 0, size_t(B) * l.nblk * sizeof(unsigned long long), s0));
-        const long long cells = (long long)dimz * dimy * dimx;
         const int blocks = (int)((cells * B + 255) / 256 > 16384 ? 16384 : (cells * B + 255) / 256);
         hipLaunchKernelGGL(k_build_cells, dim3(blocks), dim3(256), 0, s0, (const long long *)occ, cell_of_id,
                            mask64, dimz, dimy, dimx, l.nby, l.nbx, l.nblk, B, (long long)n_rows);
@@ -163,6 +188,9 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
                            near2, dimz, dimy, dimx, l.nbz, l.nby, l.nbx, l.nblk, B);
         sp.end();
         if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
+        rec.B = B; rec.dimz = dimz; rec.dimy = dimy; rec.dimx = dimx; rec.n_rows = n_rows;
+        rec.builds++;
+        accel_put(workspace, rec);
     }
 
     if (pipe) {
@@ -402,6 +430,11 @@ int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx, const fl
     return VP_OK;
 }
 
+long long vp_workspace_table_builds(const void *workspace)
+{
+    return accel_get(workspace).builds;
+}
+
 int vp_workspace_release(void *workspace)
 {
     std::lock_guard<std::mutex> g(g_pipe_mu);
@@ -424,6 +457,8 @@ int vp_workspace_release(void *workspace)
         }
     for (size_t i = 0; i < g_last_hit.size(); i++)
         if (g_last_hit[i].first == workspace) { g_last_hit.erase(g_last_hit.begin() + i); break; }
+    for (size_t i = 0; i < g_accel.size(); i++)
+        if (g_accel[i].first == workspace) { g_accel.erase(g_accel.begin() + i); break; }
     return VP_OK;
 }
 

@@ -85,6 +85,31 @@ struct PipeState {
     long long calls = 0;
     int last_q = 0;
 };
+// Host-side record of the occupancy-derived tables held by a workspace: the shape they were built for, whether the
+// workspace also holds the 32-bit copy of the grid they were built from (VP_FLAG_VERIFY_ACCEL), and how often they
+// have been built (vp_workspace_table_builds).  Guarded by g_pipe_mu.
+struct AccelRecord {
+    int B = 0, dimz = 0, dimy = 0, dimx = 0;
+    long long n_rows = 0;
+    bool copy_valid = false;
+    long long builds = 0;
+};
+std::vector<std::pair<const void *, AccelRecord>> g_accel;
+AccelRecord accel_get(const void *workspace)
+{
+    std::lock_guard<std::mutex> g(g_pipe_mu);
+    for (auto &kv : g_accel)
+        if (kv.first == workspace) return kv.second;
+    return AccelRecord();
+}
+void accel_put(const void *workspace, const AccelRecord &r)
+{
+    std::lock_guard<std::mutex> g(g_pipe_mu);
+    for (auto &kv : g_accel)
+        if (kv.first == workspace) { kv.second = r; return; }
+    g_accel.emplace_back(workspace, r);
+}
+
 // offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
 std::vector<std::pair<const void *, size_t>> g_last_hit;
 void remember_hit(const void *workspace, size_t off)
@@ -134,7 +159,7 @@ struct Params {
     long long n_rows;
 };
 
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_WORDS = 64 };
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
@@ -150,6 +175,7 @@ struct ViewEntry {
 // ------------------------------------------------------------------------------------------------
 struct Layout {
     size_t cell_of_id, mask64, near2, dist, dist_tmp;    // occupancy-derived tables (shared)
+    size_t occ_copy;                                     // (int)occupancy the tables were built from (VP_FLAG_VERIFY_ACCEL)
     size_t status[2], cnt_call[2], heavy[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
     size_t total;
     int nbx, nby, nbz;
@@ -175,6 +201,7 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
     l.near2 = off;       off += align256(size_t(B) * l.nblk * 16);
     l.dist = off;        off += align256(size_t(B) * l.nblk);
     l.dist_tmp = off;    off += align256(size_t(B) * l.nblk);
+    l.occ_copy = off;    off += align256(size_t(B) * size_t(dimz) * dimy * dimx * sizeof(int));
     for (int q = 0; q < 2; q++) {
         l.cnt_call[q] = off; off += align256(size_t(n_rows) * sizeof(int));
         l.heavy[q] = off;    off += align256(size_t(n_rows) * sizeof(int));

@@ -61,6 +61,21 @@ __global__ __launch_bounds__(256) void k_build_cells(const long long *__restrict
     }
 }
 
+// VP_FLAG_VERIFY_ACCEL: the tables depend on the grid only through (int)occ[i] (k_build_cells above).  Compare the
+// caller's grid with the 32-bit copy taken when the tables were built, refresh the copy where it differs, and
+// raise *differs if any cell changed.
+__global__ __launch_bounds__(256) void k_occ_compare_copy(const long long *__restrict__ occ, int *__restrict__ copy,
+                                                          long long n, int *differs)
+{
+    bool d = false;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int v = (int)occ[i];
+        if (copy[i] != v) { copy[i] = v; d = true; }
+    }
+    if (d) *differs = 1;
+}
+
 // Separable Chebyshev distance transform on the block grid: D = min_q max(|dx|,|dy|,|dz|) factors into
 // three 1-D passes because max distributes over min.  axis 0: along x from the masks; 1: y; 2: z.
 __global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__restrict__ mask64,

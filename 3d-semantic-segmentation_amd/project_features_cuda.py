@@ -107,7 +107,7 @@ def project_features_cuda_py(encoded_2d_features, occupancy_3D, viewMatrixInv, i
     _host.project_features_raw(
         encoded_2d_features, occupancy_3D, viewMatrixInv, intrinsicParams,
         [float(v) for v in opts_cpu.tolist()], mapping2dto3d_num, projected_features,
-        [float(v) for v in grid_origin[:3].tolist()], float(voxel_size), sync=True)
+        [float(v) for v in grid_origin[:3].tolist()], float(voxel_size), sync=True, verify_accel=True)
     return None
 
 

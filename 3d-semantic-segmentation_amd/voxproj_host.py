@@ -17,6 +17,7 @@ VP_FLAG_SYNC = 1
 VP_FLAG_REUSE_ACCEL = 2
 VP_FLAG_EXACT_MARCH = 4
 VP_FLAG_PIPELINE = 8
+VP_FLAG_VERIFY_ACCEL = 16
 
 _lib = None
 _lock = threading.Lock()
@@ -26,7 +27,7 @@ EXPORTS = [
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
     "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors",
     "vp_project_features_f16", "vp_nearest_voxel",
-    "vp_stream_read",
+    "vp_stream_read", "vp_workspace_table_builds",
 ]
 
 
@@ -113,6 +114,8 @@ def lib():
             L.vp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
             L.vp_workspace_release.restype = ctypes.c_int
             L.vp_workspace_release.argtypes = [vp]
+            L.vp_workspace_table_builds.restype = ctypes.c_longlong
+            L.vp_workspace_table_builds.argtypes = [vp]
             L.vp_project_colors.restype = ctypes.c_int
             L.vp_project_colors.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_float), ctypes.c_double, vp, ctypes.c_int,
@@ -185,7 +188,7 @@ def get_workspace(device):
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
                          workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False,
-                         views_hit=None):
+                         views_hit=None, verify_accel=False):
     """Call vp_project_features (or vp_project_features_f16 when ``feats`` is float16) on torch CUDA tensors
     (already validated by the caller).
 
@@ -197,7 +200,10 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     default from env VOXPROJ_EXACT_MARCH).  ``pipeline``: asynchronous job mode (VP_FLAG_PIPELINE): phase 1 of
     this call overlaps the previous call's gather; the caller must keep occ/vmi/intr alive and unchanged
     until ``workspace_status`` (or a device synchronise) and must not pass sync.  ``views_hit``: optional
-    int32 [n_rows] tensor, += number of views of this call that hit each voxel.
+    int32 [n_rows] tensor, += number of views of this call that hit each voxel.  ``verify_accel``: when the tables
+    are not reused by identity (blocking calls only), let the library compare the grid with the copy the tables were
+    built from and rebuild only if it changed (VP_FLAG_VERIFY_ACCEL) -- for callers that make a new, equal
+    occupancy tensor for every call.
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -214,7 +220,9 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     if exact_march is None:
         exact_march = os.environ.get("VOXPROJ_EXACT_MARCH", "0") == "1"
     flags = ((VP_FLAG_SYNC if (sync and not pipeline) else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
-             | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0))
+             | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0)
+             | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel
+                                         and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1") else 0))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream
@@ -253,6 +261,11 @@ def counters(ws, device):
     stream = torch.cuda.current_stream(device).cuda_stream
     check(lib().vp_workspace_counters(ptr, arr, 8, stream))
     return dict(bad_id=int(arr[0]), box_miss=int(arr[1]), n_heavy=int(arr[2]))
+
+
+def table_builds(ws):
+    """How many times the occupancy-derived tables of workspace ``ws`` have been built (diagnostic)."""
+    return int(lib().vp_workspace_table_builds(ws.ptr()))
 
 
 def profile_enable(on=True):

@@ -44,7 +44,7 @@ enum {
                                 rebuilding them                                                    */
     VP_FLAG_EXACT_MARCH = 4, /* A/B arm: evaluate every ray sample like K.cu:47-82 does instead of
                                 leaping over provably empty space (same results, slower)           */
-    VP_FLAG_PIPELINE = 8     /* asynchronous job mode (excludes VP_FLAG_SYNC): phase 1 (ray-march) runs on a
+    VP_FLAG_PIPELINE = 8,    /* asynchronous job mode (excludes VP_FLAG_SYNC): phase 1 (ray-march) runs on a
                                 library-owned side stream -- held to a few wavefronts per CU -- so that the
                                 march of this call overlaps the gather of the previous call on the same
                                 workspace (two buffer sets alternate; heavy voxels on a third stream).  The
@@ -53,6 +53,12 @@ enum {
                                 still pending on `stream`, keeps them alive and unchanged until the stream
                                 has been synchronised (vp_workspace_status does), and uses one stream per
                                 workspace.                                                            */
+    VP_FLAG_VERIFY_ACCEL = 16  /* blocking calls only (ignored with VP_FLAG_PIPELINE or VP_FLAG_REUSE_ACCEL): the
+                                workspace has not been written by anyone else since the previous call on it;
+                                compare the occupancy grid with the 32-bit copy kept from the call that built
+                                the tables (one pass over the grid + a 4-byte read-back) and rebuild them only
+                                if a cell, the shape or n_rows changed.  For callers that pass a NEW tensor with
+                                the SAME contents on every call, as debug_project_features.py:143 does.       */
 };
 
 int vp_abi_version(void);
@@ -194,6 +200,10 @@ int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx,
  * VP_FLAG_PIPELINE (drains them first); call before freeing or recycling the workspace memory.
  */
 int vp_workspace_release(void *workspace);
+
+/* How many times the occupancy-derived tables of this workspace have been (re)built so far (0 if never);
+ * diagnostic for VP_FLAG_REUSE_ACCEL / VP_FLAG_VERIFY_ACCEL. */
+long long vp_workspace_table_builds(const void *workspace);
 
 /*
  * Copies the first-hit ID image i32 [B,V,H,W] of the LAST vp_project_features call on this

@@ -287,7 +287,20 @@ def test_occupancy_tables_follow_the_tensor_not_its_address(oracle_mod):
     occ_np = s.occ.copy()
     occ_t = torch.from_numpy(occ_np[None].astype(np.int64)).to(dev)
     check(occ_t, occ_np)
+    builds = voxproj_host.table_builds(_last_ws())
     check(occ_t, occ_np)                                  # same tensor again: tables reused
+    check(occ_t.clone(), occ_np)                          # a new tensor with equal contents (DPF:143): verified, reused
+    check(torch.from_numpy(occ_np[None].astype(np.int64)).to(dev), occ_np)
+    assert voxproj_host.table_builds(_last_ws()) == builds
+    one = occ_t.clone()
+    cell = tuple(int(v) for v in np.argwhere(occ_np == 0)[7])
+    one[0][cell] = 5                                      # a new tensor that differs in ONE cell: rebuilt
+    occ_one = occ_np.copy()
+    occ_one[cell] = 5
+    check(one, occ_one)
+    assert voxproj_host.table_builds(_last_ws()) == builds + 1
+    check(occ_t, occ_np)                                  # and back
+    assert voxproj_host.table_builds(_last_ws()) == builds + 2
     zs = occ_np.shape[0]
     occ_np[: zs // 2] = 0                                 # in-place edit of the same tensor
     occ_t[:, : zs // 2] = 0
