@@ -277,7 +277,7 @@ def main():
                 inflight[i] = [dist.all_reduce(o, async_op=True), dist.all_reduce(c, async_op=True)]
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
-    hit_px, touched, gather_bytes, cnt, max_px = 0, 0, 0, {}, 0
+    hit_px, touched, gather_bytes, cnt, max_px, heavy_px = 0, 0, 0, {}, 0, 0
     out.zero_()
     for ci in range(len(calls)):
         count.zero_()
@@ -285,7 +285,13 @@ def main():
         ph, nt = int(count.sum().item()), int((count > 0).sum().item())
         hit_px += ph
         touched += nt
-        gather_bytes += ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
+        # k_gather proper: voxels above the library's per-call threshold (256 + 64*B*V pixels) are summed by
+        # k_gather_heavy, so their rows and output RMW do not count for this kernel
+        heavy = count > (int(os.environ.get("VOXPROJ_HEAVY_T", "0")) or (256 + 64 * len(calls[ci][1])))
+        ph_heavy, nt_heavy = int(count[heavy].sum().item()), int(heavy.sum().item())
+        heavy_px += ph_heavy
+        gather_bytes += ((ph - ph_heavy) * C * esize + (nt - nt_heavy) * C * 4 * 2 + len(calls[ci][1]) * H * W * 4
+                         + n_rows * 4 * 2)
         c1 = voxproj_host.counters(ws, dev)
         for k in c1:
             cnt[k] = cnt.get(k, 0) + c1[k]
@@ -357,7 +363,7 @@ def main():
                                   "gather_heavy": round(prof["heavy_ms"] / a.steps, 3),
                                   "overlapped": pipeline},
             "pool_placement": placement,
-            "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "max_pixels_per_voxel_call": max_px,
+            "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "heavy_pixels_per_step": heavy_px, "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "measured_stream_read_gbs": round(stream_gbs, 1),
