@@ -1,6 +1,7 @@
 """A/B of two builds of libvoxproj.so on the SAME feature-pool allocation (its placement moves the gather's speed by
 several per cent, so builds cannot be compared across processes): python tools/probe_ab.py libA.so libB.so [...]
-Prints mean k_gather / k_first_hit time per launch, serial phases, R2 scene, 16 views per call."""
+Prints mean k_gather / k_first_hit time per launch, serial phases (--pipeline: pipelined), R2 scene with 16 views per
+call (--r1: the R1 scene, 25 views per call)."""
 import os
 import sys
 
@@ -14,8 +15,12 @@ from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 libs = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
 pipeline = "--pipeline" in sys.argv
 dev = torch.device("cuda", 0)
-n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
-V, NCALL = 16, 8
+if "--r1" in sys.argv:      # BASELINE config 2
+    n_vox, n_views, W, H, C = 80000, 100, 484, 274, 512
+    V, NCALL = 25, 4
+else:
+    n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
+    V, NCALL = 16, 8
 s = make_scene(n_vox, n_views, W, H, seed=0)
 occ = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
 c2w = torch.from_numpy(s.c2w).to(dev)
