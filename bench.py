@@ -325,6 +325,13 @@ def main():
         last = voxproj_host.counters(ws, dev)
         assert last["bad_id"] == 0 and last["box_miss"] == 0, last
     voxproj_host.profile_enable(False)
+    if dist is not None and not os.environ.get("VOXPROJ_BENCH_NOVERIFY"):
+        # the buffer reduced last holds the whole scene on every rank: its hit-count total must equal the sum of the
+        # ranks' own (pre-pass) totals, exactly
+        t = torch.tensor([hit_px], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        last_c = bufs[(state["k"] - 1) % len(bufs)][1]
+        assert int(last_c.sum().item()) == int(t.item()), "all-reduced hit counts do not add up to the ranks' totals"
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
