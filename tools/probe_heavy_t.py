@@ -1,0 +1,56 @@
+"""Per-call pixel counts per voxel (the gather's task sizes) and the effect of the heavy-voxel threshold on one
+allocation: python tools/probe_heavy_t.py [--pipeline]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-semantic-segmentation_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import voxproj_host  # noqa: E402
+from synthetic_scene import make_features_torch, make_scene  # noqa: E402
+
+pipeline = "--pipeline" in sys.argv
+dev = torch.device("cuda", 0)
+n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
+V, NCALL = 32, 4
+s = make_scene(n_vox, n_views, W, H, seed=0)
+occ = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+c2w = torch.from_numpy(s.c2w).to(dev)
+intr = torch.from_numpy(s.intr[None]).to(dev)
+opts = [float(v) for v in s.opts()]
+origin = [float(v) for v in s.grid_origin]
+vmis = [c2w[i * V:(i + 1) * V].reshape(-1).contiguous() for i in range(NCALL)]
+feats = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
+make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
+count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
+out = torch.zeros(n_vox + 1, C, dtype=torch.float32, device=dev)
+ws = voxproj_host.Workspace()
+
+voxproj_host.project_features_raw(feats, occ, vmis[0], intr, opts, count, out, origin, s.voxel_size, workspace=ws, sync=True)
+c = count.cpu().numpy().astype(np.int64)
+tot = c.sum()
+print(f"call 0: {int((c > 0).sum())} voxels touched, {tot} pixels, max {c.max()}")
+for t in (100, 200, 300, 500, 700, 1000, 1500, 2304):
+    m = c > t
+    print(f"  > {t:5d} px: {int(m.sum()):6d} voxels, {100.0 * c[m].sum() / tot:5.2f} % of the pixels")
+
+for T in (2304, 1500, 1000, 700, 500, 300, 200, 2304):
+    os.environ["VOXPROJ_HEAVY_T"] = str(T)
+    count.zero_(); out.zero_()
+    for rep in range(3):
+        voxproj_host.profile_enable(rep > 0)
+        if rep == 1:
+            torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+        for ci in range(NCALL):
+            voxproj_host.project_features_raw(feats, occ, vmis[ci], intr, opts, count, out, origin, s.voxel_size,
+                                              workspace=ws, sync=False, reuse_accel=True, pipeline=pipeline)
+        if pipeline:
+            voxproj_host.workspace_status(ws, dev)
+        torch.cuda.synchronize()
+    e1.record(); torch.cuda.synchronize()
+    p = voxproj_host.profile_read()
+    voxproj_host.profile_enable(False)
+    n = max(p["gather_launches"], 1)
+    print(f"heavy_t {T:5d}: gather {p['gather_ms'] / n:.3f} ms/launch  heavy {p['heavy_ms'] / n:.3f}  march {p['first_hit_ms'] / n:.3f}  "
+          f"wall {e0.elapsed_time(e1) / (2 * NCALL):.3f} ms/call", flush=True)
