@@ -624,3 +624,82 @@ def test_randomized_differential_against_the_oracle(oracle_mod):
         r, _, _ = _compare(oracle_mod, feats, occ[None], c2w, intr, opts, origin, vs, n + 1, expect_boxmiss=None)
         n_hit_cases += int((r["hits"] > 0).any())
     assert n_hit_cases > 30
+
+
+def test_randomized_job_mode_against_the_oracle(oracle_mod, monkeypatch):
+    # the raw API the way a job drives it: batches of grids (B 1..3), many views per call (up to 70), sequences of
+    # pipelined or plain calls accumulating into the same outputs, fp32 or fp16 feature maps, heavy-voxel thresholds
+    # low enough to send voxels down the workgroup path, the optional per-view hit counter.  Counts and view counts
+    # exact, sums within 1e-4 of the oracle's float64 accumulation.
+    import voxproj_host
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(777)
+    saw_heavy = 0
+    for case in range(24):
+        B = int(rng.integers(1, 4))
+        dims = rng.integers(4, 28, 3)
+        n_ids = int(rng.integers(5, 400))
+        occ = np.zeros((B, *dims), np.int32)
+        for b in range(B):
+            n = min(n_ids, int(occ[b].size * float(rng.uniform(0.01, 0.3))) + 1)
+            idx = rng.choice(occ[b].size, n, replace=False)
+            occ[b].reshape(-1)[idx] = rng.choice(n_ids, n, replace=False) + 1
+        vs = float(np.float32(rng.uniform(0.05, 0.3)))
+        origin = rng.uniform(-1, 1, 3).astype(np.float32)
+        ext = dims[::-1] * vs
+        W, H = int(rng.integers(4, 36)), int(rng.integers(4, 28))
+        C = int(rng.choice([8, 16, 40]))
+        f16 = bool(rng.integers(0, 2))
+        pipeline = bool(rng.integers(0, 2))
+        monkeypatch.setenv("VOXPROJ_HEAVY_T", str(int(rng.choice([3, 20, 100000000]))))
+        f = float(rng.uniform(0.5, 2.0)) * W
+        intr = np.stack([np.array([f, f, W * rng.uniform(0.3, 0.7), H * rng.uniform(0.3, 0.7)], np.float32) for _ in range(B)])
+        opts = np.array([W, H, 0.01, float(2.0 * np.linalg.norm(ext)), float(np.float32(vs * rng.uniform(0.3, 1.2)))], np.float32)
+        n_rows = n_ids + 1
+        count = np.zeros(n_rows, np.int32)
+        out = np.zeros((n_rows, C), np.float32)
+        out64 = np.zeros((n_rows, C), np.float64)
+        views = np.zeros(n_rows, np.int64)
+        count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        out_t = torch.zeros(n_rows, C, device=dev)
+        views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        occ_t = torch.from_numpy(occ.astype(np.int64)).to(dev)
+        intr_t = torch.from_numpy(intr).to(dev)
+        ws = voxproj_host.Workspace()
+        keep = []
+        for call in range(int(rng.integers(1, 4))):
+            V = int(rng.choice([1, 2, 5, 17, 70]))
+            c2w = np.zeros((B, V, 4, 4), np.float32)
+            for b in range(B):
+                for v in range(V):
+                    c2w[b, v, :3, :3] = _random_rotation(rng)
+                    c2w[b, v, :3, 3] = origin + rng.uniform(-0.3, 1.3, 3) * ext
+                    c2w[b, v, 3, 3] = 1
+            feats = rng.standard_normal((B, V, H, W, C)).astype(np.float32)
+            if f16:
+                feats = feats.astype(np.float16).astype(np.float32)
+            r = oracle_mod.project_features(feats, occ.astype(np.int64), c2w.reshape(-1), intr, opts, origin, vs, count, out,
+                                            want_f64=True)
+            assert r["rc"] == 0
+            out64 += r["out64"]
+            for b in range(B):
+                for v in range(V):
+                    ids = np.unique(r["hits"][b, v])
+                    views[ids[ids > 0]] += 1
+            ft = torch.from_numpy(feats).to(dev)
+            ft = ft.half() if f16 else ft
+            vm = torch.from_numpy(c2w).reshape(-1).to(dev)
+            keep.append((ft, vm))
+            voxproj_host.project_features_raw(ft, occ_t, vm, intr_t, [float(v) for v in opts], count_t, out_t,
+                                              [float(v) for v in origin], vs, workspace=ws, sync=not pipeline,
+                                              reuse_accel=None, pipeline=pipeline, views_hit=views_t)
+            if pipeline:
+                voxproj_host.workspace_status(ws, dev)      # needed before the counters below, not between calls in general
+            saw_heavy += voxproj_host.counters(ws, dev)["n_heavy"] > 0
+        voxproj_host.workspace_status(ws, dev)
+        assert np.array_equal(count_t.cpu().numpy(), count), case
+        assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views), case
+        scale = np.abs(out64).max() + 1e-30
+        assert np.abs(out_t.cpu().numpy().astype(np.float64) - out64).max() <= 1e-4 * scale, case
+        ws.release()
+    assert saw_heavy >= 3
