@@ -263,3 +263,41 @@ def test_color_entry_point_end_to_end(tmp_path, oracle_mod):
     assert np.array_equal(r["hit_count"].numpy(), np.array([counts[k] for k in keys]))
     exp = np.stack([sums[k] / np.float32(counts[k]) for k in keys]).astype(np.float32)
     assert r["avg_color"].numpy().tobytes() == exp.tobytes()
+
+
+def test_rgb_kernel_randomized_against_the_oracle(oracle_mod):
+    # debug_project_colors.py:54-81 semantics on random grids, poses (cameras inside, outside and behind voxels),
+    # intrinsics and image sizes: voxel order, rounded pixel coordinates and colours bit for bit (float64 math,
+    # half-to-even rounding, image-bounds rejection, cam.z <= 0 skipped)
+    from debug_project_colors import project_colors_view
+    rng = np.random.default_rng(4242)
+    seen = 0
+    for case in range(40):
+        dims = rng.integers(2, 24, 3)
+        occ = np.zeros(dims, np.int32)
+        n = max(1, int(occ.size * float(rng.uniform(0.01, 0.4))))
+        idx = rng.choice(occ.size, n, replace=False)
+        occ.reshape(-1)[idx] = rng.permutation(n) + 1
+        vs = float(rng.uniform(0.02, 0.4))
+        origin = rng.uniform(-2, 2, 3).astype(np.float32)
+        ext = dims[::-1] * vs
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+        c2w[:3, 3] = origin + rng.uniform(-0.8, 1.8, 3) * ext
+        iw, ih = int(rng.integers(2, 90)), int(rng.integers(2, 70))
+        f = float(rng.uniform(0.3, 2.0)) * iw
+        # half-integer principal points put many projections exactly on .5 (banker's rounding matters)
+        intr = np.array([f, f * rng.uniform(0.9, 1.1), rng.choice([iw / 2, iw / 2 + 0.5]), rng.choice([ih / 2, ih / 2 + 0.5])], np.float32)
+        img = rng.integers(0, 256, (ih, iw, 3), dtype=np.uint8)
+        colors, zyx, uv = oracle_mod.rgb_project(occ, c2w, intr, origin, vs, img)
+        out = project_colors_view(torch.from_numpy(occ), torch.from_numpy(c2w), torch.from_numpy(intr), torch.from_numpy(origin),
+                                  vs, img, device=DEV)
+        assert np.array_equal(out["projected_indices"].numpy(), zyx), case
+        assert np.array_equal(out["pixel_indices"].numpy(), uv), case
+        assert out["projected_colors"].numpy().tobytes() == colors.tobytes(), case
+        seen += len(zyx) > 0
+    assert seen > 15
