@@ -301,3 +301,25 @@ def test_rgb_kernel_randomized_against_the_oracle(oracle_mod):
         assert out["projected_colors"].numpy().tobytes() == colors.tobytes(), case
         seen += len(zyx) > 0
     assert seen > 15
+
+
+def test_nearest_voxel_map_randomized_against_brute_force():
+    # exhaustive float64 nearest neighbour (what sklearn's KDTree with k=1 returns, voxeltoGaussian_logits.py:87-96) on
+    # random clouds: clustered and sparse voxel sets, queries far outside the voxel bounding box, single-voxel sets
+    from voxel_to_gaussian_map import map_gaussians_to_voxels
+    rng = np.random.default_rng(99)
+    for case in range(12):
+        n = int(rng.choice([1, 2, 17, 500, 4000]))
+        m = int(rng.choice([1, 33, 3000]))
+        scale = float(rng.choice([0.05, 1.0, 40.0]))
+        if case % 3 == 0:       # voxel-like: integer lattice points times a voxel size
+            vox = (rng.integers(-30, 30, (n, 3)) * 0.032 * scale).astype(np.float32)
+            vox = np.unique(vox, axis=0)
+        else:
+            vox = (rng.standard_normal((n, 3)) * scale).astype(np.float32)
+        mu = (rng.standard_normal((m, 3)) * scale * float(rng.choice([0.5, 1.0, 6.0]))).astype(np.float32)
+        got = map_gaussians_to_voxels(torch.from_numpy(vox), torch.from_numpy(mu), device=DEV).numpy()
+        d = ((mu[:, None, :].astype(np.float64) - vox[None, :, :].astype(np.float64)) ** 2).sum(2)
+        best = d.min(1)
+        assert got.shape == (m,) and got.min() >= 0 and got.max() < len(vox)
+        assert np.array_equal(d[np.arange(m), got], best), case       # a true nearest neighbour (ties may differ in index)
