@@ -93,9 +93,8 @@ def main(argv=None):
         arr = np.load(os.path.join(args.lseg_dir, fname))
         feats.append(upsample_features(arr, tuple(args.image_size) if args.image_size else None))
         intr, c2w = camera_for(entry, cams, args.downsample_factor)
-        intrs.append(intr)
-        if args.downsample_factor is not None:      # PTD:143 and :162 both append
-            intrs.append(camera_for(entry, cams, None)[0])
+        intrs.append(intr)                          # PTD:143 (scaled) or PTD:152 (no factor)
+        intrs.append(camera_for(entry, cams, None)[0])   # PTD:162 appends the unscaled row again, always
         exts.append(c2w)
     if not feats:
         raise RuntimeError("No valid feature/camera pairs found!")

@@ -1,0 +1,112 @@
+"""Host-side mirrors of the reference's packing script (prepare_tensor_data.py) on the CPU: camera conventions,
+JSON schema, feature up-sampling contract, and the tensor_data.pt schema."""
+import json
+import os
+
+import numpy as np
+import torch
+
+
+def _rot(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def test_camera_for_inverts_world_to_camera_and_scales_intrinsics():
+    import prepare_tensor_data as ptd
+    rng = np.random.default_rng(5)
+    R, t = _rot(rng), rng.standard_normal(3)
+    entry = {"camera_id": 3, "R": R.tolist(), "tvec": t.tolist()}
+    cams = {"3": {"params": [600.0, 610.0, 320.0, 240.0]}, "4": {"params": [500.0, 100.0, 80.0]}}
+    intr, c2w = ptd.camera_for(entry, cams, downsample_factor=0.5)
+    assert intr.dtype == torch.float32 and intr.tolist() == [300.0, 305.0, 160.0, 120.0]       # PTD:132-143
+    w2c = np.eye(4)
+    w2c[:3, :3], w2c[:3, 3] = R, t
+    assert np.abs(w2c @ c2w.numpy().astype(np.float64) - np.eye(4)).max() < 1e-6              # PTD:165-172
+    # float32 arithmetic like the reference: R^T and -R^T t formed in float32
+    R32, t32 = R.astype(np.float32), t.astype(np.float32)
+    assert c2w.numpy()[:3, 3].tobytes() == (-R32.T @ t32).tobytes()
+    intr3, _ = ptd.camera_for(dict(entry, camera_id=4), cams)                                  # simple-pinhole: fy = fx
+    assert intr3.tolist() == [500.0, 500.0, 100.0, 80.0]
+
+
+def test_load_camera_params_accepts_dict_and_list(tmp_path):
+    import prepare_tensor_data as ptd
+    a = {"images": {"1": {"name": "IMG_1", "camera_id": 1, "R": np.eye(3).tolist(), "tvec": [0, 0, 0]}},
+         "cameras": {"1": {"params": [1, 1, 0, 0]}}}
+    b = dict(a, images=list(a["images"].values()))
+    for i, d in enumerate((a, b)):
+        p = tmp_path / f"c{i}.json"
+        p.write_text(json.dumps(d))
+        by_name, cams = ptd.load_camera_params(str(p))
+        assert list(by_name) == ["IMG_1"] and by_name["IMG_1"]["camera_id"] == 1 and "1" in cams
+
+
+def test_upsample_features_contract():
+    import prepare_tensor_data as ptd
+    C, h, w = 5, 6, 9
+    rng = np.random.default_rng(6)
+    arr = rng.standard_normal((C, h, w)).astype(np.float16)
+    same = ptd.upsample_features(arr)                                       # no size: only the layout changes
+    assert same.dtype == torch.float32 and same.shape == (h, w, C)
+    assert np.array_equal(same.numpy(), arr.astype(np.float32).transpose(1, 2, 0))
+    up = ptd.upsample_features(arr, size=(12, 18))
+    assert up.shape == (12, 18, C) and up.dtype == torch.float32 and up.is_contiguous()
+    # PTD:126 casts the resized map back to fp16 before widening: every value is fp16-representable
+    assert np.array_equal(up.numpy(), up.numpy().astype(np.float16).astype(np.float32))
+    kept = ptd.upsample_features(arr, size=(12, 18), keep_dtype=True)
+    assert kept.dtype == torch.float16 and np.array_equal(kept.float().numpy(), up.numpy())
+    # bilinear with half-pixel centres: constants stay, values stay inside the range of their neighbours,
+    # and a 2x up-sample reproduces the 0.25/0.75 stencil away from the border
+    const = ptd.upsample_features(np.full((2, 4, 4), 0.5, np.float16), size=(8, 8))
+    assert (const == 0.5).all()
+    assert up.min() >= float(arr.min()) and up.max() <= float(arr.max())
+    a32 = arr.astype(np.float32)
+    exp = (0.75 * (0.75 * a32[:, 2, 3] + 0.25 * a32[:, 2, 4]) + 0.25 * (0.75 * a32[:, 3, 3] + 0.25 * a32[:, 3, 4]))
+    assert np.allclose(up.numpy()[5, 7, :], exp.astype(np.float16).astype(np.float32), atol=2e-3)
+
+
+def test_prepare_tensor_data_main_writes_the_reference_schema(tmp_path):
+    import prepare_tensor_data as ptd
+    rng = np.random.default_rng(7)
+    lseg = tmp_path / "feats"
+    lseg.mkdir()
+    names = ["DSC_0002", "DSC_0001", "DSC_0003"]
+    for n in names:
+        np.save(lseg / f"{n}.npy", rng.standard_normal((4, 5, 7)).astype(np.float16))
+    np.save(lseg / "no_camera.npy", np.zeros((4, 5, 7), np.float16))
+    cams = {"images": {str(i): {"name": n, "camera_id": 1, "R": _rot(rng).tolist(), "tvec": rng.standard_normal(3).tolist()}
+                       for i, n in enumerate(names)},
+            "cameras": {"1": {"params": [700.0, 700.0, 350.0, 250.0]}}}
+    (tmp_path / "cam.json").write_text(json.dumps(cams))
+    occ = torch.zeros(3, 4, 5, dtype=torch.int32)
+    occ[1, 2, 3] = 1
+    torch.save(occ, tmp_path / "occ.pt")
+    out = tmp_path / "tensor_data.pt"
+    ptd.main(["--lseg_dir", str(lseg), "--scaled_camera_params", str(tmp_path / "cam.json"), "--occupancy", str(tmp_path / "occ.pt"),
+              "--voxel_size", "0.05", "--grid_origin", "1", "2", "3", "--max_images", "10", "--output", str(out),
+              "--image_size", "10", "14", "--downsample_factor", "0.5"])
+    d = torch.load(out)
+    assert set(d) == {"encoded_2d_features", "occupancy_3D", "intrinsicParams", "viewMatrixInv", "grid_origin", "voxel_size"}
+    assert d["encoded_2d_features"].shape == (1, 3, 10, 14, 4) and d["encoded_2d_features"].dtype == torch.float32
+    assert d["viewMatrixInv"].shape == (1, 3, 4, 4) and d["viewMatrixInv"].dtype == torch.float32
+    # PTD:143 and :162 both append when a downsample factor is given: two intrinsics rows per view,
+    # the scaled one first -- index 0 is what debug_project_features.py:146 reads
+    assert d["intrinsicParams"].shape == (1, 6, 4)
+    assert d["intrinsicParams"][0, 0].tolist() == [350.0, 350.0, 175.0, 125.0]
+    assert d["intrinsicParams"][0, 1].tolist() == [700.0, 700.0, 350.0, 250.0]
+    assert torch.equal(d["occupancy_3D"], occ) and d["voxel_size"] == 0.05
+    assert d["grid_origin"].dtype == torch.float32 and d["grid_origin"].tolist() == [1.0, 2.0, 3.0]
+    # without a factor the reference still appends twice (PTD:152 and :162): two identical rows per view
+    ptd.main(["--lseg_dir", str(lseg), "--scaled_camera_params", str(tmp_path / "cam.json"), "--occupancy", str(tmp_path / "occ.pt"),
+              "--voxel_size", "0.05", "--grid_origin", "1", "2", "3", "--max_images", "2", "--output", str(tmp_path / "t2.pt")])
+    d2 = torch.load(tmp_path / "t2.pt")
+    assert d2["encoded_2d_features"].shape == (1, 2, 5, 7, 4) and d2["intrinsicParams"].shape == (1, 4, 4)
+    assert d2["intrinsicParams"][0, 0].tolist() == d2["intrinsicParams"][0, 1].tolist() == [700.0, 700.0, 350.0, 250.0]
+    # views follow the sorted file names (PTD:101-104), the file without a camera entry is skipped
+    first = np.load(lseg / "DSC_0001.npy")
+    assert torch.equal(d["encoded_2d_features"][0, 0], ptd.upsample_features(first, (10, 14)))
