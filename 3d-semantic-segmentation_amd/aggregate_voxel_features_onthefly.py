@@ -235,10 +235,15 @@ def main(argv=None):
             print(f"[CHECKPOINT] Saved consolidated checkpoint data after {idx} images")
     if batch_f:
         agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
-    if agg is None:
-        raise RuntimeError("no view could be processed")
     if world > 1:
+        # every rank must reach the all-reduce: agree first that each of them had something to project
+        ok = torch.tensor([int(agg is not None)], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError("a rank had no usable view (fewer views with camera entries than ranks)")
         agg.all_reduce()
+    elif agg is None:
+        raise RuntimeError("no view could be processed")
     if rank == 0:
         r = agg.result()
         n_done = agg.n_seen
