@@ -182,12 +182,18 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # VOXPROJ_SINGLE_DEVICE=1 + VOXPROJ_DIST_BACKEND=gloo: rehearse the multi-rank path on a one-GPU box
+    single = os.environ.get("VOXPROJ_SINGLE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if single else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         assert args.mode == "fast", "multi-GPU aggregation needs --mode fast"
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VOXPROJ_DIST_BACKEND", "nccl")          # nccl IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     os.makedirs(args.checkpoint_dir, exist_ok=True)
 
     voxel_size, grid_origin, grid_shape, n_from_name = bso.extract_voxel_params(args.voxel_ply)   # AGG:92

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -135,15 +136,13 @@ def test_rgb_aggregator_matches_reference_dict_semantics():
     assert r["avg_color"].numpy().tobytes() == exp_avg.tobytes()
 
 
-def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
-    # aggregate_voxel_features_onthefly.main() on files laid out like the reference's inputs: voxel-grid PLY with header
-    # comments (AGG:65-92), camera JSON (PTD:56-72), fp16 .npy features [C,h,w] (script/extract_lseg_features.py:97).
-    # parity / fast / fast+fp16 modes must agree where they should.
+def _write_scene_files(tmp_path, n_views=5, C=16):
+    """Files laid out like the reference's inputs: voxel-grid PLY with header comments (AGG:65-92), camera JSON
+    (PTD:56-72), fp16 .npy features [C,h,w] (script/extract_lseg_features.py:97).  Returns (scene, ply, lseg_dir, cam_json)."""
     import json
 
-    import aggregate_voxel_features_onthefly as agg
     from synthetic_scene import make_scene
-    s = make_scene(1500, 5, 48, 32, seed=91, room=(5.0, 4.0, 2.4))
+    s = make_scene(1500, n_views, 48, 32, seed=91, room=(5.0, 4.0, 2.4))
     ply = tmp_path / f"scene_{s.n_vox}vox_grid.ply"
     with open(ply, "w") as f:
         f.write("ply\nformat ascii 1.0\n")
@@ -155,8 +154,8 @@ def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
     lseg = tmp_path / "features"
     lseg.mkdir()
     rng = np.random.default_rng(91)
-    images, C = {}, 16
-    for v in range(5):
+    images = {}
+    for v in range(n_views):
         name = f"DSC{v:05d}.JPG"
         np.save(lseg / f"{name}.npy", rng.standard_normal((C, 16, 24)).astype(np.float16))      # half-res map, upsampled x2
         c2w = s.c2w[v].astype(np.float64)
@@ -167,6 +166,13 @@ def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
     cams = {"1": {"params": [float(x) * 2 for x in s.intr], "width": 96, "height": 64}}
     cam_json = tmp_path / "camera_params.json"
     cam_json.write_text(json.dumps({"images": images, "cameras": cams}))
+    return s, ply, lseg, cam_json
+
+
+def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
+    # aggregate_voxel_features_onthefly.main() on files: parity / fast / fast+fp16 modes must agree where they should.
+    import aggregate_voxel_features_onthefly as agg
+    s, ply, lseg, cam_json = _write_scene_files(tmp_path)
     outs = {}
     for mode, extra in (("parity", []), ("fast", []), ("fast16", ["--half_features"])):
         out_dir = tmp_path / mode
@@ -185,6 +191,29 @@ def test_entry_point_end_to_end_on_synthetic_files(tmp_path):
     assert torch.equal(outs["parity"]["voxel_coords"][pa], outs["fast"]["voxel_coords"][fa])
     a, b = outs["parity"]["avg_feats"][pa].float(), outs["fast"]["avg_feats"][fa].float()
     assert (a - b).abs().max() <= 2e-2 * b.abs().max()
+
+
+def test_entry_point_two_ranks_match_one(tmp_path):
+    # torchrun with two ranks (views r::2, one all-reduce of {sum, count, views}); gloo on one GPU rehearses the RCCL path.
+    # Integer outputs equal the single-process run's, fp32 sums differ only by the order of the two partial sums.
+    import subprocess
+
+    import aggregate_voxel_features_onthefly as agg
+    s, ply, lseg, cam_json = _write_scene_files(tmp_path, n_views=7)
+    common = ["--mode", "fast", "--lseg_dir", str(lseg), "--cam_params", str(cam_json), "--voxel_ply", str(ply), "--views_per_call", "2"]
+    agg.main(common + ["--checkpoint_dir", str(tmp_path / "one")])
+    env = dict(os.environ, VOXPROJ_SINGLE_DEVICE="1", VOXPROJ_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    script = os.path.join(ROOT, "3d-semantic-segmentation_amd", "aggregate_voxel_features_onthefly.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", script] + common + ["--checkpoint_dir", str(tmp_path / "two")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    name = f"ALL_nonzero_voxel_features_7_vox{s.n_vox}_fp32.pt"
+    one, two = torch.load(tmp_path / "one" / name), torch.load(tmp_path / "two" / name)
+    for k in ("voxel_ids", "voxel_coords", "count", "hit_count"):
+        assert torch.equal(one[k], two[k]), k
+    assert (one["sum"] - two["sum"]).abs().max() <= 1e-5 * one["sum"].abs().max()
+    assert (one["avg_feats"].float() - two["avg_feats"].float()).abs().max() <= 2e-3 * one["avg_feats"].float().abs().max()
 
 
 def test_nearest_voxel_map_matches_reference_kdtree():
