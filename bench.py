@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--pool-tries", type=int, default=3,
+    ap.add_argument("--pool-tries", type=int, default=5,
                     help="allocate the resident feature pool and the output rows this many times and keep the placement "
                          "with the fastest pass (untimed set-up; every try is reported in the JSON line); 1 = take the "
                          "first allocation as it comes")
