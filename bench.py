@@ -325,6 +325,16 @@ def main():
         last = voxproj_host.counters(ws, dev)
         assert last["bad_id"] == 0 and last["box_miss"] == 0, last
     voxproj_host.profile_enable(False)
+    if dist is None:
+        # one more pass timed exactly like the placement tries (after the timed region; diagnostic only)
+        for rep in range(2):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for ci in range(len(calls)):
+                one_call(ci)
+            voxproj_host.workspace_status(ws, dev)
+            torch.cuda.synchronize(dev)
+            placement["ms_per_pass_after_timed_region"] = round((time.perf_counter() - t1) * 1e3, 3)
     if dist is not None and not os.environ.get("VOXPROJ_BENCH_NOVERIFY"):
         # the buffer reduced last holds the whole scene on every rank: its hit-count total must equal the sum of the
         # ranks' own (pre-pass) totals, exactly
