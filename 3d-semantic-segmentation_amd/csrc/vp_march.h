@@ -17,7 +17,9 @@ namespace {
 //   * the cell index roundf((p - origin)/vs) is taken from the product with 1/vs when that product is
 //     farther than 2^-21*|q| from a rounding boundary (then both roundings agree), and from the IEEE
 //     division otherwise;
-//   * occupancy comes from a 64-bit block mask held in registers while the ray stays in a 4x4x4 block;
+//   * near geometry the bound D is the cell's own Chebyshev distance (0..3, two 64-bit bit planes per 4x4x4 block,
+//     held in registers while the ray stays in the block); D = 0 means "this cell is occupied" and only then is
+//     the int64 grid read for the ID;
 //   * the (u,v) bounds test of K.cu:53-61 is evaluated, with the reference's exact operations, only
 //     for samples that found an occupied cell (it gates nothing else).
 // Every evaluated sample uses the reference's exact fp32 operations, so the first-hit ID is identical.
@@ -124,7 +126,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
         int cur_d = 0;
         unsigned long long cur_lo = 0ull, cur_hi = 0ull;
         int dbg_leap = 0, dbg_fine = 0;
-        // binade cache of the closed-form t advance (see advance_steps): valid while t < bT2
+        // binade cache of the closed-form t advance (derivation: "Closed-form advance" in vp_tables.h): valid while t < bT2
         float bT2 = 0.0f, bTu = 0.0f, bg = 0.0f, brg = 0.0f;
         while (t < tEnd) {
             const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
@@ -176,8 +178,8 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
             }
             if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
             // advance by 1 + J samples, J = floor((D - 1.5) / dcell) of them provably unable to reach an occupied
-            // cell; the running sum t is reproduced exactly by the closed form of advance_steps, with the binade
-            // constants cached across evaluations
+            // cell; the running sum t is reproduced exactly by the closed form, with the binade constants cached
+            // across evaluations
             int S = 1 + (D >= 2 ? (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f) : 0);
             for (;;) {
                 if (t >= bT2) {
