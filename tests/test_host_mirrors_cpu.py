@@ -1,7 +1,6 @@
 """Host-side mirrors of the reference's packing script (prepare_tensor_data.py) on the CPU: camera conventions,
 JSON schema, feature up-sampling contract, and the tensor_data.pt schema."""
 import json
-import os
 
 import numpy as np
 import torch

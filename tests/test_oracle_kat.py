@@ -2,7 +2,6 @@
 oracle/projector_oracle.c (K1 wall, K2 occlusion, K3 miss, K4 accumulate,
 K5 RGB).  These pin the oracle; the reference itself holds no fixture for this path."""
 import numpy as np
-import pytest
 
 
 def _wall_scene(planes, dim=(8, 17, 17)):

@@ -5,7 +5,7 @@ is cycled (1000 x 6.1 MB = 6.1 GB would fit, 64 are used to keep set-up short)."
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "3d-semantic-segmentation_amd"))
-import numpy as np, torch, voxproj_host
+import torch, voxproj_host
 from synthetic_scene import make_scene
 dev = torch.device("cuda:0")
 N, V, W, H = 500000, 1000, 1752, 1168
