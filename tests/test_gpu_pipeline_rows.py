@@ -352,3 +352,34 @@ def test_nearest_voxel_map_randomized_against_brute_force():
         best = d.min(1)
         assert got.shape == (m,) and got.min() >= 0 and got.max() < len(vox)
         assert np.array_equal(d[np.arange(m), got], best), case       # a true nearest neighbour (ties may differ in index)
+
+
+def test_integration_md_binding_stub_runs(oracle_mod):
+    # the ctypes stub printed in INTEGRATION.md section 2 is executed as it stands (library path resolved) and must give
+    # the oracle's counts and sums
+    import re
+
+    from synthetic_scene import make_features_np, make_scene
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", txt, flags=re.S)
+    stub = next(b for b in blocks if "ctypes.CDLL" in b)
+    stub = stub.replace('ctypes.CDLL("libvoxproj.so")',
+                        f'ctypes.CDLL({os.path.join(ROOT, "3d-semantic-segmentation_amd", "libvoxproj.so")!r})')
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    s = make_scene(2000, 3, 40, 24, seed=71, room=(5.0, 4.0, 2.4))
+    C = 8
+    feats = make_features_np(3, 24, 40, C, seed=71)[None]
+    n_rows = s.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    oracle_mod.project_features(feats, s.occ[None].astype(np.int64), s.c2w.reshape(-1), s.intr[None], s.opts(), s.grid_origin,
+                                s.voxel_size, count, out)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=DEV)
+    out_t = torch.zeros(n_rows, C, device=DEV)
+    ns["project_features_cuda"](torch.from_numpy(feats).to(DEV), torch.from_numpy(s.occ[None].astype(np.int64)).to(DEV),
+                                torch.from_numpy(s.c2w).reshape(-1).to(DEV), torch.from_numpy(s.intr[None]).to(DEV),
+                                torch.from_numpy(s.opts()), count_t, out_t, torch.tensor([False]), torch.from_numpy(s.grid_origin),
+                                float(s.voxel_size))
+    assert np.array_equal(count_t.cpu().numpy(), count) and count.sum() > 0
+    assert out_t.cpu().numpy().tobytes() == out.tobytes()
