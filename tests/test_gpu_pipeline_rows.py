@@ -383,3 +383,37 @@ def test_integration_md_binding_stub_runs(oracle_mod):
                                 float(s.voxel_size))
     assert np.array_equal(count_t.cpu().numpy(), count) and count.sum() > 0
     assert out_t.cpu().numpy().tobytes() == out.tobytes()
+
+
+def test_c_abi_from_a_plain_hip_program(tmp_path, oracle_mod):
+    # examples/abi_example.cpp: libvoxproj.so driven from C++ with hipMalloc'd buffers -- no torch in the process.
+    # Its printed counts and sums (two accumulating calls on the K1 wall scene) must equal the oracle's.
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    pkg = os.path.join(ROOT, "3d-semantic-segmentation_amd")
+    exe = tmp_path / "abi_example"
+    subprocess.run([hipcc, "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "abi_example.cpp"),
+                    "-L" + pkg, "-lvoxproj", "-Wl,-rpath," + pkg, "-o", str(exe)], check=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "abi 1 rows 290"
+    Z, Y, X, H, W, C = 8, 17, 17, 16, 16, 4
+    occ = np.zeros((1, Z, Y, X), np.int64)
+    occ[0, 5] = 1 + np.arange(Y * X).reshape(Y, X)
+    feats = ((np.arange(H * W, dtype=np.float32).reshape(H, W, 1)) + np.float32(0.25) * np.arange(C, dtype=np.float32)).astype(np.float32)
+    count = np.zeros(290, np.int32)
+    out = np.zeros((290, C), np.float32)
+    for _ in range(2):
+        oracle_mod.project_features(feats[None, None], occ, np.eye(4, dtype=np.float32).reshape(-1), np.array([[8, 8, 8, 8]], np.float32),
+                                    np.array([W, H, 0.01, 10.0, 0.5], np.float32), np.array([-8, -8, 0], np.float32), 1.0, count, out)
+    got = {}
+    for ln in lines[1:]:
+        t = ln.split()
+        got[int(t[1])] = (int(t[3]), [float(v) for v in t[5:9]])
+    ids = np.nonzero(count)[0]
+    assert sorted(got) == ids.tolist() and len(ids) > 50
+    for i in ids:
+        assert got[i][0] == count[i]
+        assert np.array_equal(np.array(got[i][1], np.float32), out[i]), i      # %.9g round-trips float32
