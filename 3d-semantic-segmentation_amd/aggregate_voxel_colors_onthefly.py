@@ -29,14 +29,17 @@ class VoxelColorAggregator:
         self.first_view = torch.full((self.n_rows,), _NEVER, dtype=torch.int32, device=self.dev)
         self.n_seen = 0
 
-    def add_views(self, images_u8, c2w, intr):
-        """images u8 [V,H,W,3], c2w f32 [V,4,4], intr f32 [V,4] (per-view intrinsics, DPC:64)."""
+    def add_views(self, images_u8, c2w, intr, want_uv=False):
+        """images u8 [V,H,W,3], c2w f32 [V,4,4], intr f32 [V,4] (per-view intrinsics, DPC:64).  With ``want_uv``
+        returns the sampled pixel per view and voxel ID, int32 [V,n_rows,2] ((-1,-1) where unseen)."""
         V = int(images_u8.shape[0])
+        uv = torch.empty(V, self.n_rows, 2, dtype=torch.int32, device=self.dev) if want_uv else None
         voxproj_host.project_colors_raw(self.occ, c2w.to(self.dev, torch.float32).contiguous(),
                                         intr.to(self.dev, torch.float32).contiguous(), self.grid_origin,
                                         self.voxel_size, images_u8.to(self.dev).contiguous(), self.csum, self.hits,
-                                        first_view=self.first_view, view_base=self.n_seen)
+                                        first_view=self.first_view, view_base=self.n_seen, pixel_uv=uv)
         self.n_seen += V
+        return uv
 
     def result(self):
         zyx = (self.occ > 0).nonzero(as_tuple=False)                   # raster (z,y,x)

@@ -69,8 +69,11 @@ class VoxelFeatureAggregator:
         if mode == "parity":
             self.run16 = torch.zeros(n, C, dtype=torch.float16, device=self.dev)   # AGG voxel_feature_sum (fp16)
             self.first_view = torch.full((n,), _NEVER, dtype=torch.int32, device=self.dev)
+            # per-view scratch: zero here, and zero again after every view (the epilogue clears the rows it consumed)
             self._cnt = torch.zeros(n, dtype=torch.int32, device=self.dev)
             self._sum = torch.zeros(n, C, dtype=torch.float32, device=self.dev)
+            self._nonfinite = torch.zeros(max(1, MAX_IMAGES), dtype=torch.int32, device=self.dev)   # AGG:303-304, per view
+            self._reported = 0
         else:
             self.sum32 = torch.zeros(n, C, dtype=torch.float32, device=self.dev)
             self.count = torch.zeros(n, dtype=torch.int32, device=self.dev)
@@ -86,22 +89,27 @@ class VoxelFeatureAggregator:
         intr = intr4.reshape(1, 4).to(self.dev, torch.float32).contiguous()
         c2w = c2w.to(self.dev, torch.float32).contiguous()
         if self.mode == "parity":
+            # One projector call per view (DPF runs once per image), then ONE hand-written epilogue over the rows that
+            # view hit (vp_aggregate_view_f16): fp32 pixel sums -> fp16 (DPF:252) -> first-time clone / fp16 "+="
+            # (AGG:309-312), views += 1 (AGG:313), first_view for the dict order; the epilogue leaves the scratch pair
+            # zeroed, so nothing of size [n_rows, C] is filled, cast or blended per view.  Everything is queued on the
+            # current stream; nothing blocks until flush().
+            self._keep = getattr(self, "_keep", [])
+            vmis = c2w.reshape(V, 16)
+            self._keep.append((feats, vmis, intr))
+            if self.n_seen + V > self._nonfinite.numel():
+                grown = torch.zeros(2 * (self.n_seen + V), dtype=torch.int32, device=self.dev)
+                grown[:self._nonfinite.numel()] = self._nonfinite
+                self._nonfinite = grown
             for v in range(V):
-                self._cnt.zero_()
-                self._sum.zero_()
-                voxproj_host.project_features_raw(feats[v:v + 1].unsqueeze(0), self.occ, c2w[v].reshape(-1), intr,
+                voxproj_host.project_features_raw(feats[v:v + 1].unsqueeze(0), self.occ, vmis[v], intr,
                                                   self._opts(W, H), self._cnt, self._sum, self.grid_origin,
-                                                  self.voxel_size, workspace=self.ws, sync=True, reuse_accel=None)
-                hit = (self._cnt > 0) & self.valid_id                      # DPF:237,246-248
-                rows16 = self._sum.to(torch.float16)                       # DPF:252
-                first = hit & (self.views == 0)
-                again = hit & (self.views > 0)
-                # AGG:309-312: first time feat.clone(), afterwards an fp16 "+=" (float add rounded to half)
-                self.run16 = torch.where(first[:, None], rows16, self.run16)
-                self.run16 = torch.where(again[:, None], (self.run16.float() + rows16.float()).to(torch.float16), self.run16)
-                self.first_view = torch.where(first, torch.full_like(self.first_view, self.n_seen), self.first_view)
-                self.views += hit.to(torch.int32)                          # AGG:313
+                                                  self.voxel_size, workspace=self.ws, sync=False, reuse_accel=None)
+                voxproj_host.aggregate_view_f16(self._sum, self._cnt, self.run16, self.views, self.first_view,
+                                                self.n_seen, self._nonfinite[self.n_seen:self.n_seen + 1])
                 self.n_seen += 1
+            if len(self._keep) > 8:
+                self.flush()
         else:
             # keep every argument of a pipelined call alive until the stream is drained
             self._keep = getattr(self, "_keep", [])
@@ -115,9 +123,16 @@ class VoxelFeatureAggregator:
                 self.flush()
 
     def flush(self):
-        if self.mode != "parity":
+        """Drain the stream, surface device-side errors, and (parity mode) report the views whose float16 rows held a
+        NaN or Inf, as the reference does after every image (AGG:303-304)."""
+        if self.ws.buf is not None:
             voxproj_host.workspace_status(self.ws, self.dev)
-            self._keep = []
+        self._keep = []
+        if self.mode == "parity" and self.n_seen > self._reported:
+            bad = torch.nonzero(self._nonfinite[self._reported:self.n_seen]).reshape(-1).tolist()
+            for v in bad:
+                print(f"[STEP 3][ERROR] NaN or Inf detected in projected features for view {self._reported + v}")
+            self._reported = self.n_seen
 
     def all_reduce(self):
         """Combine the ranks' partial {sum, count, views} (fast mode; one RCCL all-reduce each)."""

@@ -107,7 +107,18 @@ def voxel_coords(points, grid_origin, voxel_size):
 
 
 def build_occupancy(points, grid_origin, voxel_size, device="cpu"):
-    """Dense int32 [Z,Y,X] grid with occ[z,y,x] = vertex index + 1, last duplicate wins (BSO:44-46)."""
+    """Dense int32 [Z,Y,X] grid with occ[z,y,x] = vertex index + 1, last duplicate wins (BSO:44-46).
+
+    On a CUDA device the whole of BSO:30-53 runs as two hand-written HIP kernels (vp_voxel_coords, vp_scatter_occupancy
+    in csrc/vp_prep.h); the numpy / torch-CPU expression below is the command-line script's own host path (the
+    reference script is a CPU program)."""
+    if torch.device(device).type == "cuda":
+        import voxproj_host
+        pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
+        occ, lo = voxproj_host.build_occupancy_device(pts, grid_origin, voxel_size)
+        if min(lo) < 0:
+            print(f"Warning: negative min coords {np.array(lo)}, will offset to zero")
+        return occ
     coords, dims = voxel_coords(points, grid_origin, voxel_size)
     dx, dy, dz = (int(v) for v in dims)
     lin = torch.from_numpy((coords[:, 2] * dy + coords[:, 1]) * dx + coords[:, 0]).to(device)

@@ -26,6 +26,8 @@
 //   vp_march.h   phase 1 (k_first_hit)
 //   vp_gather.h  phase 2 (k_gather, k_gather_heavy)
 //   vp_aux.h     RGB projection, nearest-voxel map, streaming-read probe
+//   vp_prep.h    feature-map up-sampler (PTD:119-127), occupancy builder (BSO:30-53)
+//   vp_aggregate.h  the aggregator's per-view fp16 accumulate over the hit rows (AGG:307-313)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include <hip/hip_runtime.h>
@@ -47,6 +49,8 @@
 #include "vp_march.h"
 #include "vp_gather.h"
 #include "vp_aux.h"
+#include "vp_prep.h"
+#include "vp_aggregate.h"
 
 // ------------------------------------------------------------------------------------------------
 // host helpers
@@ -54,13 +58,18 @@
 // VEC_OK: 0 = scalar fp32 path, 1 = 16-byte vector fp32 path, 2 = fp16 feature maps
 #define VP_DISPATCH_KVU(KERNEL, VEC_OK, C, ...)                                   \
     do {                                                                          \
-        if ((VEC_OK) == 2) hipLaunchKernelGGL((KERNEL<1, 8, 4>), __VA_ARGS__);    \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((KERNEL<1, 8, VP_F16_U>), __VA_ARGS__);    \
         else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((KERNEL<2, 4, 4>), __VA_ARGS__); \
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
 
 constexpr int HEAVY_BLOCKS = 128;
+
+// rows in flight per wavefront in the fp16 gather
+#ifndef VP_F16_U
+#define VP_F16_U 4
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
@@ -150,6 +159,19 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const bool verify = (flags & VP_FLAG_VERIFY_ACCEL) && !pipe && !(flags & VP_FLAG_REUSE_ACCEL);
     const int cmp_blocks = (int)((cells * B + 255) / 256 > 8192 ? 8192 : (cells * B + 255) / 256);
     bool rebuild = !(flags & VP_FLAG_REUSE_ACCEL);
+    // VP_FLAG_REUSE_ACCEL is a promise about the tables in THIS workspace: refuse it when the library never built
+    // them here (fresh or recycled memory) or built them for another grid shape / row count -- the march would leap on
+    // garbage and silently miss hits
+    if (!rebuild && (rec.builds == 0 || !rec_matches))
+        return fail(VP_EINVAL, "VP_FLAG_REUSE_ACCEL, but this workspace holds no occupancy tables for a grid of this shape "
+                               "(B, dims, n_rows): call once without the flag");
+    if (!rec.status_init) {
+        // first call on this workspace memory: the sticky error words must start from zero
+        VP_HIP(hipMemsetAsync(ws + l.status[0], 0, l.status[1] - l.status[0] + ST_WORDS * sizeof(int), s0));
+        VP_HIP(hipStreamSynchronize(s0));
+        rec.status_init = true;
+        accel_put(workspace, rec);
+    }
     if (verify && rec_matches && rec.copy_valid) {
         int differs = 1;
         VP_HIP(hipMemsetAsync(status + ST_OCCDIFF, 0, sizeof(int), s0));
@@ -205,7 +227,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (getenv("VOXPROJ_DEBUG_EVALS")) heavy_t = -1;   // diagnostics only: the hit image then holds evaluation counts
     {
         ProfSpan sp; sp.begin(0, s1);
-        VP_HIP(hipMemsetAsync(status, 0, ST_WORDS * sizeof(int), s1));
+        VP_HIP(hipMemsetAsync(status, 0, ST_CALL_WORDS * sizeof(int), s1));
         VP_HIP(hipMemsetAsync(cnt_call, 0, size_t(n_rows) * sizeof(int), s1));
         hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
         sp.end();
@@ -214,7 +236,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         FirstHitArgs fa;
         fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
         fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
-        fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status;
+        fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status; fa.sticky = (int *)(ws + l.status[0]);
         const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
         ProfSpan sp; sp.begin(1, s1);
         if (flags & VP_FLAG_EXACT_MARCH) {
@@ -240,6 +262,14 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
 
     // ---- phase 2 ----
+    {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            const int v = getenv("VOXPROJ_F16_PLAIN") ? 1 : 0;
+            VP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exp_plain_loads), &v, sizeof(int)));
+        }
+    }
     GatherArgs g;
     g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
@@ -339,15 +369,22 @@ int vp_workspace_status(void *workspace, void *stream_)
 {
     if (!workspace) return fail(VP_EINVAL, "null workspace");
     static_assert(ST_WORDS * sizeof(int) == 256, "status block is one 256-byte slot");
+    static_assert(ST_STICKY_STUCK == ST_STICKY_BADID + 1 && ST_STICKY_BADID >= ST_CALL_WORDS, "sticky words sit behind the per-call ones");
     int st[2 * ST_WORDS];
     int rc = read_status(workspace, (hipStream_t)stream_, st);
     if (rc != VP_OK) return rc;
-    PipeState *ps = pipe_state(workspace, false);
-    const bool second = ps && (ps->used[1] || ps->calls > 1);
-    if (st[ST_STUCK] || (second && st[ST_WORDS + ST_STUCK]))
+    if (!accel_get(workspace).status_init) return VP_OK;   // no call has run on this workspace yet
+    // the sticky words collect the errors of EVERY call since the last vp_workspace_status (the per-call words of a
+    // buffer set are cleared when the set is reused two pipelined calls later); reading them clears them
+    const int stuck = st[ST_STICKY_STUCK], badid = st[ST_STICKY_BADID];
+    if (stuck || badid) {
+        VP_HIP(hipMemsetAsync((int *)workspace + ST_STICKY_BADID, 0, 2 * sizeof(int), (hipStream_t)stream_));
+        VP_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    }
+    if (stuck)
         return fail(VP_EINVAL, "rayIncrement is too small to advance a float32 ray parameter near depthMax: the reference "
                                "loop would never terminate (those rays were skipped, outputs are incomplete)");
-    if (st[ST_BADID] || (second && st[ST_WORDS + ST_BADID]))
+    if (badid)
         return fail(VP_EBADID, "a ray hit an occupancy ID outside [1, n_rows): outputs are too small for the grid's IDs");
     return VP_OK;
 }
@@ -405,28 +442,137 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
     return VP_OK;
 }
 
+size_t vp_colors_workspace_bytes(int64_t n_rows)
+{
+    if (n_rows <= 0) return 0;
+    return 256 + align256(size_t(n_rows) * sizeof(int));
+}
+
 int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx, const float *c2w, const float *intr,
                       int V, const float *grid_origin_host, double voxel_size, const uint8_t *images,
                       int img_h, int img_w, float *color_sum, int32_t *hit_count, int32_t *first_view,
-                      int64_t n_rows, int view_base, int32_t *status_dev, void *stream_)
+                      int32_t *pixel_uv, int64_t n_rows, int view_base, void *workspace, size_t workspace_bytes,
+                      void *stream_)
 {
-    if (!occ || !c2w || !intr || !grid_origin_host || !images || !color_sum || !hit_count || !status_dev)
+    if (!occ || !c2w || !intr || !grid_origin_host || !images || !color_sum || !hit_count || !workspace)
         return fail(VP_EINVAL, "null pointer argument");
     if (dimz <= 0 || dimy <= 0 || dimx <= 0 || V <= 0 || img_h <= 0 || img_w <= 0 || n_rows <= 0)
         return fail(VP_EINVAL, "non-positive dimension");
     const long long cells = (long long)dimz * dimy * dimx;
-    if (cells >= (1ll << 31)) return fail(VP_EINVAL, "occupancy grid has >= 2^31 cells");
+    if (cells >= (1ll << 31) || n_rows >= (1ll << 31)) return fail(VP_EINVAL, "occupancy grid or row count >= 2^31");
+    if (workspace_bytes < vp_colors_workspace_bytes(n_rows))
+        return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, vp_colors_workspace_bytes(n_rows));
+    if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
-    VP_HIP(hipMemsetAsync(status_dev, 0, ST_WORDS * sizeof(int), stream));
-    hipLaunchKernelGGL(k_project_colors, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, (const int *)occ,
-                       dimz, dimy, dimx, c2w, intr, V, grid_origin_host[0], grid_origin_host[1], grid_origin_host[2],
-                       voxel_size, (const unsigned char *)images, img_h, img_w, color_sum, (int *)hit_count,
-                       (int *)first_view, (long long)n_rows, view_base, (int *)status_dev);
-    VP_HIP(hipGetLastError());
-    int st[ST_WORDS];
-    VP_HIP(hipMemcpyAsync(st, status_dev, sizeof(st), hipMemcpyDeviceToHost, stream));
+    int *status = (int *)workspace;
+    int *cell_of_id = (int *)((char *)workspace + 256);
+    VP_HIP(hipMemsetAsync(status, 0, 256, stream));
+    VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(n_rows) * sizeof(int), stream));
+    const int cb = (int)((cells + 255) / 256 > 16384 ? 16384 : (cells + 255) / 256);
+    hipLaunchKernelGGL(k_color_cells, dim3(cb), dim3(256), 0, stream, (const int *)occ, cells, cell_of_id, (long long)n_rows, status);
+    int st[2];
+    VP_HIP(hipMemcpyAsync(st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
-    if (st[ST_BADID]) return fail(VP_EBADID, "an occupancy ID is outside [1, n_rows): outputs are too small for the grid's IDs");
+    if (st[CST_BADID]) return fail(VP_EBADID, "an occupancy ID is outside [1, n_rows): outputs are too small for the grid's IDs");
+    if (st[CST_DUP]) return fail(VP_EINVAL, "an occupancy ID labels more than one cell: the colour path needs unique IDs "
+                                            "(build_sparse_occupancy.py:44-46 produces them)");
+    hipLaunchKernelGGL(k_project_colors, dim3((unsigned)((n_rows - 1 + 255) / 256)), dim3(256), 0, stream, (const int *)cell_of_id,
+                       dimy, dimx, c2w, intr, V, grid_origin_host[0], grid_origin_host[1], grid_origin_host[2],
+                       voxel_size, (const unsigned char *)images, img_h, img_w, color_sum, (int *)hit_count,
+                       (int *)first_view, (int *)pixel_uv, (long long)n_rows, view_base);
+    VP_HIP(hipGetLastError());
+    VP_HIP(hipStreamSynchronize(stream));
+    return VP_OK;
+}
+
+size_t vp_upsample_workspace_bytes(int C, int h, int w, int src_is_f16)
+{
+    if (C <= 0 || h <= 0 || w <= 0) return 0;
+    return align256(size_t(C) * h * w * (src_is_f16 ? 2 : 4));
+}
+
+int vp_upsample_features(const void *src_chw, int src_is_f16, int C, int h, int w, void *dst_hwc, int dst_is_f16,
+                         int H, int W, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (!src_chw || !dst_hwc || !workspace) return fail(VP_EINVAL, "null pointer argument");
+    if (C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return fail(VP_EINVAL, "non-positive dimension");
+    if (dst_is_f16 && !src_is_f16) return fail(VP_EINVAL, "a float16 destination needs a float16 source (PTD:126 casts back to the file's dtype)");
+    if ((long long)H * W >= (1ll << 31) || (long long)h * w >= (1ll << 31)) return fail(VP_EINVAL, "image has >= 2^31 pixels");
+    if (workspace_bytes < vp_upsample_workspace_bytes(C, h, w, src_is_f16))
+        return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, vp_upsample_workspace_bytes(C, h, w, src_is_f16));
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long P = (long long)h * w;
+    const dim3 tgrid((unsigned)((P + 63) / 64), (unsigned)((C + 63) / 64));
+    // cv::resize derives the scale from the destination size: inv_scale = dsize / ssize, scale = 1 / inv_scale
+    const double scale_x = 1.0 / ((double)W / (double)w), scale_y = 1.0 / ((double)H / (double)h);
+    const unsigned ublocks = (unsigned)(((long long)H * W + 3) / 4);
+#define VP_UPS(TS_, TD_, VEC_) hipLaunchKernelGGL((k_upsample_hwc<TS_, TD_, VEC_>), dim3(ublocks), dim3(256), 0, stream, \
+        (const TS_ *)workspace, (TD_ *)dst_hwc, C, h, w, H, W, scale_x, scale_y)
+    const bool al16 = (((uintptr_t)workspace | (uintptr_t)dst_hwc) & 15) == 0;
+    if (src_is_f16) {
+        hipLaunchKernelGGL((k_chw_to_hwc<_Float16>), tgrid, dim3(256), 0, stream, (const _Float16 *)src_chw, (_Float16 *)workspace, C, P);
+        const bool v8 = al16 && C % 8 == 0;
+        if (dst_is_f16) { if (v8) VP_UPS(_Float16, _Float16, 8); else VP_UPS(_Float16, _Float16, 1); }
+        else { if (v8) VP_UPS(_Float16, float, 8); else VP_UPS(_Float16, float, 1); }
+    } else {
+        hipLaunchKernelGGL((k_chw_to_hwc<float>), tgrid, dim3(256), 0, stream, (const float *)src_chw, (float *)workspace, C, P);
+        if (al16 && C % 4 == 0) VP_UPS(float, float, 4); else VP_UPS(float, float, 1);
+    }
+#undef VP_UPS
+    VP_HIP(hipGetLastError());
+    return VP_OK;
+}
+
+int vp_voxel_coords(const float *points_xyz, int64_t N, const float *grid_origin_host, float voxel_size,
+                    int32_t *coords, int32_t *scratch8_dev, int32_t *minmax_host, void *stream_)
+{
+    if (!points_xyz || !grid_origin_host || !coords || !scratch8_dev || !minmax_host) return fail(VP_EINVAL, "null pointer argument");
+    if (N <= 0 || N >= (1ll << 31) - 1) return fail(VP_EINVAL, "point count must be in [1, 2^31 - 2]");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int init[8] = {2147483647, 2147483647, 2147483647, -2147483647 - 1, -2147483647 - 1, -2147483647 - 1, 0, 0};
+    VP_HIP(hipMemcpyAsync(scratch8_dev, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_voxel_coords, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, points_xyz, (long long)N,
+                       grid_origin_host[0], grid_origin_host[1], grid_origin_host[2], voxel_size, (int *)coords,
+                       (int *)scratch8_dev, (int *)scratch8_dev + 6);
+    VP_HIP(hipGetLastError());
+    int back[8];
+    VP_HIP(hipMemcpyAsync(back, scratch8_dev, sizeof(back), hipMemcpyDeviceToHost, stream));
+    VP_HIP(hipStreamSynchronize(stream));
+    if (back[6]) return fail(VP_EINVAL, "a point's voxel coordinate is not finite or beyond 2^30 cells from the grid origin");
+    memcpy(minmax_host, back, 6 * sizeof(int));
+    return VP_OK;
+}
+
+int vp_scatter_occupancy(const int32_t *coords, int64_t N, const int32_t *shift3_host, int dimz, int dimy, int dimx,
+                         int32_t *occ, int32_t *scratch8_dev, void *stream_)
+{
+    if (!coords || !shift3_host || !occ || !scratch8_dev) return fail(VP_EINVAL, "null pointer argument");
+    if (N <= 0 || N >= (1ll << 31) - 1 || dimz <= 0 || dimy <= 0 || dimx <= 0) return fail(VP_EINVAL, "bad size");
+    if ((long long)dimz * dimy * dimx >= (1ll << 31)) return fail(VP_EINVAL, "occupancy grid has >= 2^31 cells");
+    hipStream_t stream = (hipStream_t)stream_;
+    VP_HIP(hipMemsetAsync(occ, 0, size_t(dimz) * dimy * dimx * sizeof(int), stream));
+    VP_HIP(hipMemsetAsync(scratch8_dev, 0, 8 * sizeof(int), stream));
+    hipLaunchKernelGGL(k_scatter_occupancy, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (const int *)coords, (long long)N,
+                       shift3_host[0], shift3_host[1], shift3_host[2], dimz, dimy, dimx, (int *)occ, (int *)scratch8_dev);
+    VP_HIP(hipGetLastError());
+    int bad = 0;
+    VP_HIP(hipMemcpyAsync(&bad, scratch8_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    VP_HIP(hipStreamSynchronize(stream));
+    if (bad) return fail(VP_EINVAL, "a shifted voxel coordinate falls outside the [dimz,dimy,dimx] grid");
+    return VP_OK;
+}
+
+int vp_aggregate_view_f16(float *view_sum, int32_t *view_count, void *run16, int32_t *views, int32_t *first_view,
+                          int view_index, int32_t *nonfinite_dev, int64_t n_rows, int C, void *stream_)
+{
+    if (!view_sum || !view_count || !run16 || !views || !first_view || !nonfinite_dev) return fail(VP_EINVAL, "null pointer argument");
+    if (n_rows <= 0 || C <= 0) return fail(VP_EINVAL, "non-positive dimension");
+    if (((uintptr_t)view_sum & 15) || ((uintptr_t)run16 & 7)) return fail(VP_EINVAL, "view_sum must be 16-byte, run16 8-byte aligned");
+    if (n_rows == 1) return VP_OK;
+    hipLaunchKernelGGL(k_aggregate_view_f16, dim3((unsigned)((n_rows - 1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, view_sum,
+                       (int *)view_count, (_Float16 *)run16, (int *)views, (int *)first_view, view_index, (int *)nonfinite_dev,
+                       (long long)n_rows, C);
+    VP_HIP(hipGetLastError());
     return VP_OK;
 }
 

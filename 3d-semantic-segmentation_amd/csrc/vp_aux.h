@@ -6,30 +6,59 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // RGB path (BASELINE config 5): the reference's debug_project_colors.py:54-81 is a per-voxel Python loop --
-// voxel-driven, nearest pixel, NO occlusion test, numpy float64 arithmetic.  One lane per grid cell; an
-// occupied cell walks the views in order, so each voxel's float32 colour sum is accumulated in view order
-// exactly like aggregate_voxel_colors_onthefly.py:134-140 does (one contribution per view, no atomics).
-// Arithmetic contract: oracle_rgb_project in oracle/projector_oracle.c (separate multiplies and adds in
-// float64, IEEE divide, round-half-even).
+// voxel-driven, nearest pixel, NO occlusion test, numpy float64 arithmetic.
+//
+//   k_color_cells     one pass over the dense grid: cell_of_id[id] = cell (IDs are unique per cell when the grid comes
+//                     from build_sparse_occupancy.py:44-46; an ID found in two cells raises CST_DUP, an ID outside
+//                     [1, n_rows) CST_BADID)
+//   k_project_colors  one lane per OCCUPIED voxel (the compact ID list, not the dense grid): the lane walks the views
+//                     of the call in order, so the voxel's float32 colour sum is accumulated in view order exactly like
+//                     aggregate_voxel_colors_onthefly.py:134-140 does (one contribution per view, no atomics), and
+//                     writes the pixel (u, v) it sampled per view (DPC:76, `pixel_indices`).
+// Arithmetic contract: oracle_rgb_project in oracle/projector_oracle.c (separate multiplies and adds in float64, IEEE
+// divide, round-half-even).  img/255.0 is taken from a 256-entry table of exactly that float64 quotient rounded to
+// float32 (DPC:70,75), built in LDS by the workgroup: three correctly-rounded float64 divisions fewer per voxel-view.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ occ, int dimz, int dimy, int dimx,
+enum { CST_BADID = 0, CST_DUP = 1 };
+
+__global__ __launch_bounds__(256) void k_color_cells(const int *__restrict__ occ, long long cells, int *cell_of_id,
+                                                     long long n_rows, int *status)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+        const int id = occ[i];
+        if (id <= 0) continue;                            // DPC:50 (occ > 0)
+        if (id >= n_rows) { atomicOr(&status[CST_BADID], 1); continue; }
+        if (atomicMax(&cell_of_id[id], (int)i) >= 0) atomicOr(&status[CST_DUP], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ cell_of_id, int dimy, int dimx,
                                                         const float *__restrict__ c2w, const float *__restrict__ intr,
                                                         int V, float ox, float oy, float oz, double vs,
                                                         const unsigned char *__restrict__ img, int img_h, int img_w,
                                                         float *color_sum, int *hit_count, int *first_view,
-                                                        long long n_rows, int view_base, int *status)
+                                                        int *pixel_uv, long long n_rows, int view_base)
 {
-    const long long cells = (long long)dimz * dimy * dimx;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cells) return;
-    const int id = occ[i];
-    if (id <= 0) return;                                  // DPC:50 (occ > 0)
-    if (id >= n_rows) { atomicOr(&status[ST_BADID], 1); return; }
-    const int z = (int)(i / ((long long)dimy * dimx));
-    const int r = (int)(i - (long long)z * dimy * dimx);
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);                                                    // DPC:70,75
+    __syncthreads();
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (id >= n_rows) return;
+    const int cell = cell_of_id[id];
+    if (cell < 0) {
+        if (pixel_uv)
+            for (int v = 0; v < V; v++) {
+                pixel_uv[((long long)v * n_rows + id) * 2 + 0] = -1;
+                pixel_uv[((long long)v * n_rows + id) * 2 + 1] = -1;
+            }
+        return;
+    }
+    const int z = cell / (dimy * dimx);
+    const int r = cell - z * (dimy * dimx);
     const int y = r / dimx, x = r - y * dimx;
     const double wx = (double)ox + vs * (double)x, wy = (double)oy + vs * (double)y, wz = (double)oz + vs * (double)z;   // DPC:60
-    float sr = color_sum[(long long)id * 3 + 0], sg = color_sum[(long long)id * 3 + 1], sb = color_sum[(long long)id * 3 + 2];
+    float sr = color_sum[id * 3 + 0], sg = color_sum[id * 3 + 1], sb = color_sum[id * 3 + 2];
     int hc = hit_count[id];
     int fv = first_view ? first_view[id] : 0;
     for (int v = 0; v < V; v++) {
@@ -38,19 +67,27 @@ __global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ 
         const double cx = (double)m[0] * dx + (double)m[4] * dy + (double)m[8] * dz;                            // R^T d
         const double cy = (double)m[1] * dx + (double)m[5] * dy + (double)m[9] * dz;
         const double cz = (double)m[2] * dx + (double)m[6] * dy + (double)m[10] * dz;
-        if (!(cz > 0.0)) continue;                                                                              // DPC:65
-        const double u = (double)intr[v * 4 + 0] * (cx / cz) + (double)intr[v * 4 + 2];                         // DPC:66-67
-        const double w = (double)intr[v * 4 + 1] * (cy / cz) + (double)intr[v * 4 + 3];
-        const double ur = rint(u), vr = rint(w);                                                                // DPC:68 (half to even)
-        if (!(ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h)) continue;                    // DPC:69
-        const unsigned char *px = img + (((long long)v * img_h + (int)vr) * img_w + (int)ur) * 3;
-        sr += (float)((double)px[0] / 255.0);                                                                   // DPC:70,75; AGGC:139
-        sg += (float)((double)px[1] / 255.0);
-        sb += (float)((double)px[2] / 255.0);
-        hc += 1;                                                                                                // AGGC:140
-        fv = min(fv, view_base + v);
+        int ui = -1, vi = -1;
+        if (cz > 0.0) {                                                                                         // DPC:65
+            const double u = (double)intr[v * 4 + 0] * (cx / cz) + (double)intr[v * 4 + 2];                     // DPC:66-67
+            const double w = (double)intr[v * 4 + 1] * (cy / cz) + (double)intr[v * 4 + 3];
+            const double ur = rint(u), vr = rint(w);                                                            // DPC:68 (half to even)
+            if (ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h) {                          // DPC:69
+                ui = (int)ur; vi = (int)vr;
+                const unsigned char *px = img + (((long long)v * img_h + vi) * img_w + ui) * 3;
+                sr += lut[px[0]];                                                                               // AGGC:139
+                sg += lut[px[1]];
+                sb += lut[px[2]];
+                hc += 1;                                                                                        // AGGC:140
+                fv = min(fv, view_base + v);
+            }
+        }
+        if (pixel_uv) {
+            pixel_uv[((long long)v * n_rows + id) * 2 + 0] = ui;
+            pixel_uv[((long long)v * n_rows + id) * 2 + 1] = vi;
+        }
     }
-    color_sum[(long long)id * 3 + 0] = sr; color_sum[(long long)id * 3 + 1] = sg; color_sum[(long long)id * 3 + 2] = sb;
+    color_sum[id * 3 + 0] = sr; color_sum[id * 3 + 1] = sg; color_sum[id * 3 + 2] = sb;
     hit_count[id] = hc;
     if (first_view) first_view[id] = fv;
 }

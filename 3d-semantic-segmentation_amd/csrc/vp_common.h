@@ -93,6 +93,7 @@ struct AccelRecord {
     long long n_rows = 0;
     bool copy_valid = false;
     long long builds = 0;
+    bool status_init = false;   // the two status blocks have been zeroed once (sticky words start clean)
 };
 std::vector<std::pair<const void *, AccelRecord>> g_accel;
 AccelRecord accel_get(const void *workspace)
@@ -159,7 +160,12 @@ struct Params {
     long long n_rows;
 };
 
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5, ST_WORDS = 64 };
+// Status block (one 256-byte slot per buffer set).  Words [0, ST_CALL_WORDS) are per call: cleared when a call starts
+// on the set, read by vp_workspace_counters.  ST_STICKY_* live in the block of set 0 only, are raised together with
+// their per-call twins, survive every later call on the workspace and are cleared by vp_workspace_status alone --
+// so an error raised by pipelined call j is still there when the job finally asks, however many calls later.
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5, ST_CALL_WORDS = 8,
+       ST_STICKY_BADID = 8, ST_STICKY_STUCK = 9, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {

@@ -7,6 +7,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // phase 2: one wavefront per voxel
 // ------------------------------------------------------------------------------------------------
+__device__ int g_exp_plain_loads = 0;   // EXPERIMENT (fp16 gather): 1 = plain instead of non-temporal row loads
+
 template <int K, int VEC>
 struct Acc {
     float a[K * VEC];
@@ -25,10 +27,21 @@ __device__ __forceinline__ const float *feat_ptr(const float *base, long long el
 // raster order, and add their feature rows (channels cb .. cb+64*K*VEC) to acc.  64 lanes cover a
 // tile of tw x (64/tw) pixels, tw = smallest power of two >= box width (capped at 64), so tiles
 // and the lanes inside a tile are visited in raster order.
+// ID of the pixel this lane covers in the FIRST 64-pixel tile of the box (0 outside the box): the load scan_box would
+// issue for that tile, split off so that a caller can have the first tiles of several views in flight at once
+__device__ __forceinline__ int first_tile_id(const int *__restrict__ hv, int W, int x0, int y0, int x1, int y1, int lane)
+{
+    const int bw = x1 - x0 + 1;
+    const int lg = bw >= 64 ? 6 : (bw <= 1 ? 0 : 32 - __builtin_clz(bw - 1));
+    const int px = x0 + (lane & ((1 << lg) - 1)), py = y0 + (lane >> lg);
+    return ((px <= x1) && (py <= y1)) ? hv[py * W + px] : 0;
+}
+
 template <int K, int VEC, int U>
 __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int *__restrict__ hv,
                                          int W, int C, int id, int x0, int y0, int x1, int y1,
-                                         int cb, int lane, Acc<K, VEC> &acc, int &found)
+                                         int cb, int lane, Acc<K, VEC> &acc, int &found,
+                                         bool have_first = false, int h_first = 0)
 {
     const int bw = x1 - x0 + 1;
     const int lg = bw >= 64 ? 6 : (bw <= 1 ? 0 : 32 - __builtin_clz(bw - 1));
@@ -40,7 +53,9 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
             const int px = tx + lx;
             const bool inb = (px <= x1) && (py <= y1);
             const int pix = py * W + px;
-            const int h = inb ? hv[pix] : 0;
+            int h;
+            if (have_first && ty == y0 && tx == x0) h = h_first;     // prefetched by the caller (first_tile_id)
+            else h = inb ? hv[pix] : 0;
             unsigned long long m = __ballot(h == id);
             found += __popcll(m);
             while (m) {
@@ -66,7 +81,8 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
                             for (int k = 0; k < K; k++) {
                                 const int ch = (k * 64 + lane) * 8;
                                 if (cb + ch < C)
-                                    r[j][k] = __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
+                                    r[j][k] = g_exp_plain_loads ? *reinterpret_cast<const v8h_ *>(reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2)
+                                                                : __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
                                         reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2));
                                 else
                                     r[j][k] = (v8h_)(_Float16)0;
@@ -213,6 +229,15 @@ struct GatherArgs {
 
 constexpr int GW = 16;   // wavefronts per k_gather_heavy workgroup
 
+// views whose first ID tile is fetched together by the one-wavefront gather (1 = one view at a time)
+#ifndef VP_GATHER_G16
+#define VP_GATHER_G16 4
+#endif
+#ifndef VP_GATHER_G32
+#define VP_GATHER_G32 1
+#endif
+#define VP_GATHER_G(VEC) ((VEC) == 8 ? VP_GATHER_G16 : VP_GATHER_G32)
+
 template <int K, int VEC>
 __device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, int cb, int C, int lane)
 {
@@ -288,7 +313,7 @@ __device__ __forceinline__ float near_plane(const Params &p)
 
 // Normal role: one wavefront sums all pixels of one voxel, in (b, v, y, x) order, starting from the
 // row already in `out` -- bit-identical to the oracle's serial accumulation.
-template <int K, int VEC, int U>
+template <int K, int VEC, int U, int G>
 __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Params &p, int id, int expected, int lane)
 {
     const int W = p.width, H = p.height, C = p.C;
@@ -312,15 +337,49 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
                 bool ne = false;
                 if (v < p.V) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
                 unsigned long long vm = __ballot(ne);
+                // Views are taken G at a time: the ID-image loads of the first tile of all G views go out together (one
+                // memory latency instead of G dependent ones -- most boxes are a single 64-pixel tile, and many views of
+                // a voxel yield no pixel at all), then the views are summed one after the other, in order.
                 while (vm && found < expected) {
-                    const int l = __builtin_ctzll(vm);
-                    vm &= vm - 1;
-                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
-                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
-                    const long long bv = (long long)b * p.V + vbase + l;
-                    const int before = found;
-                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane, acc, found);
-                    nviews += found > before;
+                    // the group: the lowest G set bits of vm
+                    unsigned long long mg = 0ull;
+#pragma unroll
+                    for (int q = 0; q < G; q++)
+                        if (vm) { mg |= vm & (~vm + 1ull); vm &= vm - 1; }
+                    int gh[G];
+                    if constexpr (G > 1) {
+                        unsigned long long t = mg;
+#pragma unroll
+                        for (int q = 0; q < G; q++) {
+                            gh[q] = 0;
+                            if (t) {
+                                const int l = __builtin_ctzll(t);
+                                t &= t - 1;
+                                gh[q] = first_tile_id(g.hit + ((long long)b * p.V + vbase + l) * HW, W, __builtin_amdgcn_readlane(x0, l),
+                                                      __builtin_amdgcn_readlane(y0, l), __builtin_amdgcn_readlane(x1, l),
+                                                      __builtin_amdgcn_readlane(y1, l), lane);
+                            }
+                        }
+                    }
+                    int q = 0;
+#pragma unroll 1
+                    for (unsigned long long t = mg; t && found < expected; q++) {
+                        const int l = __builtin_ctzll(t);
+                        t &= t - 1;
+                        const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                        const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
+                        int hq = 0;
+                        if constexpr (G > 1) {
+                            hq = gh[0];
+#pragma unroll
+                            for (int k = 1; k < G; k++) hq = (q == k) ? gh[k] : hq;
+                        }
+                        const long long bv = (long long)b * p.V + vbase + l;
+                        const int before = found;
+                        scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0, bx1, by1, cb, lane,
+                                            acc, found, G > 1, hq);
+                        nviews += found > before;
+                    }
                 }
             }
         }
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     const int id = (int)idl;
     const int expected = g.cnt_call[id];
     if (expected == 0 || expected > g.heavy_t) return;
-    gather_voxel_wave<K, VEC, U>(g, p, id, expected, lane);
+    gather_voxel_wave<K, VEC, U, VP_GATHER_G(VEC)>(g, p, id, expected, lane);
 }
 
 template <int K, int VEC, int U>

@@ -38,6 +38,7 @@ struct FirstHitArgs {
     int *heavy_list;
     int heavy_t;
     int *status;
+    int *sticky;   // status block of set 0: ST_STICKY_* words (never cleared by a call)
 };
 
 template <int MODE>
@@ -90,6 +91,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     // ulp(t) <= ulp(tEnd), so it does iff adding inc changes tEnd.  Such a ray is reported, not marched.
     if ((t < tEnd) && !(tEnd + p.inc > tEnd)) {
         atomicOr(&status[ST_STUCK], 1);
+        atomicOr(&fa.sticky[ST_STICKY_STUCK], 1);
         t = tEnd;
     }
     if constexpr (!ACCEL) {
@@ -209,6 +211,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     }
     if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
         atomicOr(&status[ST_BADID], 1);
+        atomicOr(&fa.sticky[ST_STICKY_BADID], 1);
         id = 0;
     }
     hit[((long long)bv * p.height + y) * p.width + x] = id;

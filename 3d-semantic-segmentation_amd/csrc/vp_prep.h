@@ -1,0 +1,153 @@
+// vp_prep.h -- the data-format rows either side of the projector: the feature-map up-sampler that
+// replaces prepare_tensor_data.py:119-127,183-185 and the occupancy builder that replaces build_sparse_occupancy.py:30-53.
+// Included by voxproj.hip only.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Feature-map up-sampler.  The reference resizes every channel of the fp16 [C,h,w] LSeg map with
+// cv2.resize(..., INTER_LINEAR) in float32, casts the result back to the file's dtype and only then widens it to
+// float32 and permutes to channels-last (PTD:119-127,152,183-185).  Here: one transpose pass [C,h,w] -> [h,w,C]
+// (k_chw_to_hwc, 64x64 tiles through LDS) and one wavefront per output pixel that reads the four source rows
+// (16 B per lane, served by L2: every source row is used by ~(H/h)*(W/w) output pixels) and writes the C-wide output
+// row once.
+//
+// Arithmetic (the parity spec of this row -- OpenCV's published INTER_LINEAR rule for CV_32F, resize.cpp):
+//   scale_x = 1.0 / ((double)W / w)                              (double, as cv::resize derives it from dsize)
+//   fx = (float)((dx + 0.5) * scale_x - 0.5);  sx = floor(fx);  fx -= sx
+//   sx < 0      -> sx = 0, fx = 0;     sx >= w-1 -> sx = w-1, fx = 0  (the tap at sx+1 then has weight 0 and is not read)
+//   a0 = 1.f - fx, a1 = fx                                       (float)
+//   rows: fy likewise WITHOUT the edge zeroing; sy0 = clamp(sy, 0, h-1), sy1 = clamp(sy+1, 0, h-1); b0 = 1.f - fy, b1 = fy
+//   r0 = S[sy0][sx]*a0 + S[sy0][sx+1]*a1;  r1 = S[sy1][sx]*a0 + S[sy1][sx+1]*a1    (horizontal pass, float32)
+//   out = r0*b0 + r1*b1                                                               (vertical pass, float32)
+//   every multiply and add rounds separately (no FMA: the library is built -ffp-contract=off); then the cast back to
+//   the source dtype (PTD:126; binary16 round-to-nearest-even) and, for a float32 destination, the exact widening.
+// OpenCV's SIMD builds may fuse the vertical pass (v_muladd); that build-dependent last-bit choice is outside the spec,
+// see DESIGN.md.  oracle/resize_oracle.py restates the same arithmetic in numpy float32.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_chw_to_hwc(const T *__restrict__ src, T *__restrict__ dst, int C, long long P)
+{
+    // src [C,P] -> dst [P,C]; 64x64 tile, 256 threads: 16 rows of 64 per pass
+    __shared__ T tile[64][65];
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r;
+        const long long p = p0 + tx;
+        if (c < C && p < P) tile[r][tx] = src[(long long)c * P + p];
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const long long p = p0 + r;
+        const int c = c0 + tx;
+        if (c < C && p < P) dst[p * C + c] = tile[tx][r];
+    }
+}
+
+// one wavefront per output pixel, lanes over channels: VEC consecutive channels per lane (16-byte loads when
+// VEC * sizeof(TS) == 16), consecutive lanes = consecutive channel groups, so every source and destination row moves as
+// whole contiguous lines
+template <typename T, int N>
+struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T>
+struct VecOf<T, 1> { typedef T type; };
+
+template <typename TS, typename TD, int VEC>
+__global__ __launch_bounds__(256) void k_upsample_hwc(const TS *__restrict__ src, TD *__restrict__ dst, int C, int h, int w,
+                                                      int H, int W, double scale_x, double scale_y)
+{
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)H * W) return;
+    const int lane = threadIdx.x & 63;
+    const int dy = (int)(pix / W), dx = (int)(pix - (long long)dy * W);
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= w - 1) { sx = w - 1; fx = 0.f; }
+    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int sy0 = min(max(sy, 0), h - 1), sy1 = min(max(sy + 1, 0), h - 1);
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const bool two = sx < w - 1;      // at the right border OpenCV copies S[sx] (x >= xmax: D[dx] = S[sx] * 1)
+    const TS *s00 = src + ((long long)sy0 * w + sx) * C, *s10 = src + ((long long)sy1 * w + sx) * C;
+    TD *o = dst + pix * C;
+    typedef typename VecOf<TS, VEC>::type VS;
+    typedef typename VecOf<TD, VEC>::type VD;
+    for (int c = lane * VEC; c < C; c += 64 * VEC) {
+        const VS p00 = *reinterpret_cast<const VS *>(s00 + c), p10 = *reinterpret_cast<const VS *>(s10 + c);
+        VS p01 = p00, p11 = p10;
+        if (two) {
+            p01 = *reinterpret_cast<const VS *>(s00 + C + c);
+            p11 = *reinterpret_cast<const VS *>(s10 + C + c);
+        }
+        VD res;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float q00, q01, q10, q11;
+            if constexpr (VEC == 1) { q00 = (float)p00; q01 = (float)p01; q10 = (float)p10; q11 = (float)p11; }
+            else { q00 = (float)p00[e]; q01 = (float)p01[e]; q10 = (float)p10[e]; q11 = (float)p11[e]; }
+            const float r0 = two ? q00 * a0 + q01 * a1 : q00 * 1.f;
+            const float r1 = two ? q10 * a0 + q11 * a1 : q10 * 1.f;
+            const float v = r0 * b0 + r1 * b1;
+            const TS back = (TS)v;                   // PTD:126 arr_upsampled.astype(arr.dtype)
+            if constexpr (VEC == 1) res = (TD)back;  // PTD:152 .float() (exact) or kept in the file's dtype
+            else res[e] = (TD)back;
+        }
+        *reinterpret_cast<VD *>(o + c) = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occupancy builder (build_sparse_occupancy.py:30-53).  Two kernels around one 24-byte read-back (the grid's extent
+// decides the size of the tensor the caller allocates):
+//   k_voxel_coords      coords[i] = rint((pts[i] - origin) / voxel_size) in float32, round half to even (BSO:32;
+//                       numpy keeps float32: float32 array op python float), and the min / max per axis (BSO:35,40)
+//   k_scatter_occupancy occ[z,y,x] = i + 1 with "the last vertex wins" (BSO:45-46) = largest ID wins = atomicMax
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_voxel_coords(const float *__restrict__ pts, long long N, float ox, float oy, float oz,
+                                                      float vs, int *__restrict__ coords, int *minmax, int *bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c[3] = {0, 0, 0};
+    const bool live = i < N;
+    if (live) {
+        const float q[3] = {(pts[i * 3 + 0] - ox) / vs, (pts[i * 3 + 1] - oy) / vs, (pts[i * 3 + 2] - oz) / vs};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float r = rintf(q[k]);
+            if (!(fabsf(r) < 1073741824.0f)) { atomicOr(bad, 1); c[k] = 0; }   // NaN / beyond any grid: reported
+            else c[k] = (int)r;
+            coords[i * 3 + k] = c[k];
+        }
+    }
+    // wave-level min/max, one atomic pair per wave and axis
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int lo = live ? c[k] : 2147483647, hi = live ? c[k] : -2147483647 - 1;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off));
+            hi = max(hi, __shfl_xor(hi, off));
+        }
+        if ((threadIdx.x & 63) == 0 && lo <= hi) {
+            atomicMin(&minmax[k], lo);
+            atomicMax(&minmax[3 + k], hi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_occupancy(const int *__restrict__ coords, long long N, int sx, int sy, int sz,
+                                                           int dimz, int dimy, int dimx, int *occ, int *bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int x = coords[i * 3 + 0] - sx, y = coords[i * 3 + 1] - sy, z = coords[i * 3 + 2] - sz;
+    if ((unsigned)x >= (unsigned)dimx || (unsigned)y >= (unsigned)dimy || (unsigned)z >= (unsigned)dimz) { atomicOr(bad, 1); return; }
+    atomicMax(&occ[((long long)z * dimy + y) * dimx + x], (int)(i + 1));
+}
+
+}  // namespace

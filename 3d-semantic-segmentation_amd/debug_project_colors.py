@@ -3,7 +3,7 @@
 The reference (cuda_project_image_to_sparse_voxel/debug_project_colors.py:16-89) imports the CUDA extension
 but never calls it: the colour path is a per-voxel Python/numpy loop -- voxel-driven, nearest pixel, NO
 occlusion test, float64 math (DPC:54-81).  ``project_colors_view`` runs that loop as the HIP kernel
-k_project_colors (one lane per grid cell) and returns the reference's three tensors in the reference's row
+k_project_colors (one lane per occupied voxel) and returns the reference's three tensors in the reference's row
 order ((z,y,x) raster order of np.nonzero, DPC:50,58).
 """
 import argparse
@@ -26,24 +26,16 @@ def project_colors_view(occ_zyx, extr, intr4, grid_origin, voxel_size, img_np, d
     intr = intr4.reshape(1, 4).to(dev, torch.float32).contiguous()
     csum = torch.zeros(n_rows, 3, dtype=torch.float32, device=dev)
     hits = torch.zeros(n_rows, dtype=torch.int32, device=dev)
-    voxproj_host.project_colors_raw(occ, c2w, intr, [float(v) for v in grid_origin], float(voxel_size), img, csum, hits)
+    uv = torch.empty(1, n_rows, 2, dtype=torch.int32, device=dev)
+    voxproj_host.project_colors_raw(occ, c2w, intr, [float(v) for v in grid_origin], float(voxel_size), img, csum, hits,
+                                    pixel_uv=uv)
     # reference row order: raster (z,y,x) over occupied cells (DPC:50,58)
     zyx = (occ > 0).nonzero(as_tuple=False)
     ids = occ[zyx[:, 0], zyx[:, 1], zyx[:, 2]].long()
     keep = hits[ids] > 0
     zyx, ids = zyx[keep], ids[keep]
-    colors = csum[ids]                       # one contribution per voxel in a single-view call
-    # recover (u,v) for pixel_indices by matching is not needed downstream (AGGC uses indices + colours);
-    # they are recomputed with the same float64 formula on the host for the few hit voxels
-    m = extr.reshape(4, 4).double().cpu()
-    world = grid_origin.double().cpu()[None, :] + float(voxel_size) * zyx[:, [2, 1, 0]].double().cpu()
-    d = world - m[:3, 3][None, :]
-    cam = torch.stack([m[0, i] * d[:, 0] + m[1, i] * d[:, 1] + m[2, i] * d[:, 2] for i in range(3)], 1)
-    fx, fy, cx, cy = (intr4.reshape(-1)[i].double().cpu() for i in range(4))
-    u = torch.round(fx * (cam[:, 0] / cam[:, 2]) + cx)       # torch.round is half-to-even like Python round()
-    v = torch.round(fy * (cam[:, 1] / cam[:, 2]) + cy)
-    return dict(projected_colors=colors.cpu(), projected_indices=zyx.int().cpu(),
-                pixel_indices=torch.stack([u, v], 1).int())
+    # one contribution per voxel in a single-view call; (u,v) as sampled by the kernel (DPC:76)
+    return dict(projected_colors=csum[ids].cpu(), projected_indices=zyx.int().cpu(), pixel_indices=uv[0, ids].cpu())
 
 
 def main(argv=None):

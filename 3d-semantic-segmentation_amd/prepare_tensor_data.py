@@ -8,12 +8,13 @@ call them in-process:
   load_camera_params   JSON schema of PTD:56-72  ({"images": {id: {name, camera_id, R, tvec}}, "cameras":
                        {id: {params: [fx,fy,cx,cy] | [f,cx,cy]}}})
   camera_for           intrinsics x downsample factor (PTD:132-143) and c2w = [R^T | -R^T t] (PTD:165-172)
-  upsample_features    fp16 [C,h,w] -> bilinear (half-pixel centres, like cv2.INTER_LINEAR, PTD:119-127) ->
-                       cast back to the file's dtype (PTD:126) -> float32 channels-last [H,W,C] (PTD:152,183-185)
+  upsample_features    fp16 [C,h,w] -> bilinear (OpenCV's INTER_LINEAR rule, PTD:119-127) -> cast back to the file's
+                       dtype (PTD:126) -> float32 channels-last [H,W,C] (PTD:152,183-185)
 
-The resize runs as one torch ``interpolate`` (on the GPU when given a CUDA device) instead of C separate
-``cv2.resize`` calls; cv2 is third-party and unpinned in the reference (cuda_requirement.txt), so its exact
-float rounding is not part of the parity contract -- the feature tensor handed to the projector is.
+The resize is the hand-written HIP up-sampler behind the C-ABI (vp_upsample_features, csrc/vp_prep.h: one transpose pass
+and one wavefront per output pixel instead of C separate ``cv2.resize`` calls, a cast and a permute); it needs a GPU and
+there is no CPU fallback for it.  cv2 is third-party and unpinned in the reference (cuda_requirement.txt:10); the
+arithmetic is pinned to OpenCV's published rule, spelled out in csrc/vp_prep.h and restated in oracle/resize_oracle.py.
 """
 import argparse
 import json
@@ -53,17 +54,26 @@ def camera_for(entry, cams, downsample_factor=None):
     return intr, torch.from_numpy(c2w)
 
 
-def upsample_features(arr, size=None, device="cpu", keep_dtype=False):
-    """[C,h,w] array (any float dtype) -> [H,W,C] tensor on ``device``: float32 like the reference (PTD:152), or,
+def upsample_features(arr, size=None, device="cpu", keep_dtype=False, out=None):
+    """[C,h,w] array (float16 or float32) -> [H,W,C] tensor on ``device``: float32 like the reference (PTD:152), or,
     with ``keep_dtype``, in the file's own dtype (fp16 for LSeg features) -- the values are the same because
-    PTD:126 casts the resized map back to the file's dtype before widening it."""
-    t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
-    if size is not None and tuple(t.shape[1:]) != tuple(size):
-        up = torch.nn.functional.interpolate(t.float()[None], size=tuple(size), mode="bilinear", align_corners=False)[0]
-        t = up.to(t.dtype)                       # PTD:126  arr_upsampled.astype(arr.dtype)
-    if not (keep_dtype and t.dtype == torch.float16):
-        t = t.float()
-    return t.permute(1, 2, 0).contiguous()
+    PTD:126 casts the resized map back to the file's dtype before widening it.  A change of size runs on the GPU
+    (``device`` must be a CUDA device then; the result stays there unless ``device`` says "cpu" -- no: it raises)."""
+    arr = np.ascontiguousarray(arr)
+    if arr.dtype not in (np.float16, np.float32):
+        arr = arr.astype(np.float32)
+    dev = torch.device(device)
+    C, h, w = arr.shape
+    H, W = (int(v) for v in size) if size is not None else (h, w)
+    if dev.type != "cuda":
+        if (H, W) != (h, w):
+            raise RuntimeError("upsample_features: resizing runs on the GPU (vp_upsample_features); pass a CUDA device")
+        t = torch.from_numpy(arr)
+        if not (keep_dtype and t.dtype == torch.float16):
+            t = t.float()
+        return t.permute(1, 2, 0).contiguous()
+    import voxproj_host
+    return voxproj_host.upsample_features(torch.from_numpy(arr).to(dev), H, W, keep_dtype=keep_dtype, out=out)
 
 
 def main(argv=None):
@@ -77,6 +87,8 @@ def main(argv=None):
     p.add_argument("--output", required=True)
     p.add_argument("--image_size", nargs=2, type=int)
     p.add_argument("--downsample_factor", type=float, default=None)
+    p.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu",
+                   help="where the feature maps are resized (a resize needs a GPU)")
     args = p.parse_args(argv)
 
     occ = torch.load(args.occupancy)
@@ -91,7 +103,7 @@ def main(argv=None):
             print(f"[WARN] No camera entry for feature file: {fname}, skipping.")
             continue
         arr = np.load(os.path.join(args.lseg_dir, fname))
-        feats.append(upsample_features(arr, tuple(args.image_size) if args.image_size else None))
+        feats.append(upsample_features(arr, tuple(args.image_size) if args.image_size else None, device=args.device).cpu())
         intr, c2w = camera_for(entry, cams, args.downsample_factor)
         intrs.append(intr)                          # PTD:143 (scaled) or PTD:152 (no factor)
         intrs.append(camera_for(entry, cams, None)[0])   # PTD:162 appends the unscaled row again, always

@@ -1,12 +1,17 @@
-"""Drop-in for the reference's ``project_features_cuda`` extension module on MI355X.
+"""Python-side companions of the compiled drop-in module ``project_features_cuda``.
 
-The reference builds a pybind11 torch extension named ``project_features_cuda`` exposing one
-function of the same name (cuda_project_image_to_sparse_voxel/project_image_cuda.cpp:78-79,
-setup.py:10-27) and calls it from debug_project_features.py:201-208.  This module keeps that
-import name, the ten positional arguments, the in-place ``+=`` semantics of the two output tensors
-(project_image_cuda_kernel.cu:77,88), the ``None`` return and the argument checks of
-project_image_cuda.cpp:38-61 (same messages, raised as RuntimeError like TORCH_CHECK does), and
-forwards to the hand-written HIP implementation behind the C-ABI in include/voxproj.h.
+The drop-in itself is a COMPILED extension, like the reference's (cuda_project_image_to_sparse_voxel/setup.py:10-27,
+project_image_cuda.cpp:78-79): ``setup.py build_ext --inplace`` here produces ``project_features_cuda.*.so`` from
+csrc/project_features_ext.cpp, and ``import project_features_cuda`` fails -- as it does in the reference -- when it has
+not been built.  This module adds what lives beside it:
+
+  project_features_cuda_py   the same front written in Python over ctypes: the ten positional arguments, the in-place
+                             ``+=`` semantics of the two output tensors (project_image_cuda_kernel.cu:77,88), the ``None``
+                             return and the argument checks of project_image_cuda.cpp:38-61 (same messages, raised as
+                             RuntimeError like TORCH_CHECK does), ending in the same C-ABI call (include/voxproj.h).  The
+                             GPU tests run every case through both fronts; it is NOT a fallback that is picked silently.
+  last_workspace             test/diagnostic hook: the scratch buffer of the last call of either front
+  IMPLEMENTATION             "compiled" when the extension module is importable, else "python" (informational)
 
 Differences from the reference, all fenced in DESIGN.md:
   * no stdout banners / device printf (project_image_cuda.cpp:35, kernel.cu:148-156,202-254);
@@ -15,24 +20,18 @@ Differences from the reference, all fenced in DESIGN.md:
     project_image_cuda.cpp:46 vs kernel.cu:445, and is never used by the pipeline);
   * V is not limited to 16 views per call and feature offsets are 64-bit.
 
-Two fronts over the same C-ABI call, same checks and messages:
-  * ``_project_features_ext`` -- compiled pybind11 module (csrc/project_features_ext.cpp, the counterpart of
-    project_image_cuda.cpp; built by ``voxproj_host.build_ext()``), used whenever it has been built;
-  * ``project_features_cuda_py`` below -- the same front in Python over ctypes, used when the compiled module
-    is absent.  ``IMPLEMENTATION`` says which one ``project_features_cuda`` is.
-
-There is no CPU fallback: without libvoxproj.so or without a GPU tensor the call raises.
+There is no CPU fallback: without libvoxproj.so or without a GPU tensor every call raises.
 """
 import torch
 
 import voxproj_host as _host
 
 try:
-    import _project_features_ext as _ext      # needs torch imported first (libtorch, libc10_hip)
-except ImportError:                           # not built: the ctypes front below does the same job
+    import project_features_cuda as _ext      # the compiled module (needs torch imported first: libtorch, libc10_hip)
+except ImportError:
     _ext = None
 
-__all__ = ["project_features_cuda", "project_features_cuda_py", "IMPLEMENTATION", "last_workspace"]
+__all__ = ["project_features_cuda_py", "IMPLEMENTATION", "last_workspace"]
 
 
 def _check(cond, msg):
@@ -131,9 +130,4 @@ def last_workspace(device, front=None):
     return _host.get_workspace(device)
 
 
-if _ext is not None:
-    project_features_cuda = _ext.project_features_cuda
-    IMPLEMENTATION = "compiled"
-else:
-    project_features_cuda = project_features_cuda_py
-    IMPLEMENTATION = "python"
+IMPLEMENTATION = "compiled" if _ext is not None else "python"

@@ -27,7 +27,9 @@ EXPORTS = [
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
     "vp_profile_enable", "vp_profile_read", "vp_workspace_release", "vp_project_colors",
     "vp_project_features_f16", "vp_nearest_voxel",
-    "vp_stream_read", "vp_workspace_table_builds",
+    "vp_stream_read", "vp_workspace_table_builds", "vp_colors_workspace_bytes",
+    "vp_upsample_workspace_bytes", "vp_upsample_features", "vp_voxel_coords", "vp_scatter_occupancy",
+    "vp_aggregate_view_f16",
 ]
 
 
@@ -46,36 +48,27 @@ def build(force=False):
     return LIB_PATH
 
 
-EXT_PATH = os.path.join(_HERE, "_project_features_ext.so")
+def ext_path():
+    """Where ``setup.py build_ext --inplace`` puts the compiled drop-in module ``project_features_cuda``."""
+    import sysconfig
+    return os.path.join(_HERE, "project_features_cuda" + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
 def build_ext(force=False):
-    """Compile the pybind11 front of the drop-in module (csrc/project_features_ext.cpp, the counterpart of the
-    reference's project_image_cuda.cpp) against this interpreter's torch: hipcc as a host C++17 compiler, linked
-    to libvoxproj.so beside it.  Returns the path of _project_features_ext.so."""
-    import sysconfig
-    import torch
-    from torch.utils import cpp_extension
-    build()
+    """Build the compiled drop-in module with the package's setup.py (the counterpart of the reference's
+    ``python setup.py install`` step, cuda_project_image_to_sparse_voxel/setup.py:10-27), in-tree: csrc/Makefile compiles
+    the HIP kernels into libvoxproj.so, torch's BuildExtension compiles csrc/project_features_ext.cpp and links it to that
+    library.  Returns the module's path."""
+    import sys
+    build(force)
+    out = ext_path()
     src = os.path.join(_HERE, "csrc", "project_features_ext.cpp")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "voxproj.h")
-    newest = max(os.path.getmtime(src), os.path.getmtime(hdr))
-    if not force and os.path.exists(EXT_PATH) and os.path.getmtime(EXT_PATH) >= newest:
-        return EXT_PATH
-    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = ["hipcc", "-std=c++17", "-O2", "-fPIC", "-shared", "-w", src, "-o", EXT_PATH,
-           "-I" + os.path.join(os.path.dirname(_HERE), "include"), "-I" + sysconfig.get_paths()["include"]]
-    cmd += ["-I" + p for p in cpp_extension.include_paths()]
-    cmd += ["-DTORCH_EXTENSION_NAME=_project_features_ext", "-DTORCH_API_INCLUDE_EXTENSION_H", "-DUSE_ROCM",
-            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi())]
-    for name in ("_PYBIND11_COMPILER_TYPE", "_PYBIND11_STDLIB", "_PYBIND11_BUILD_ABI"):
-        val = getattr(torch._C, name, None)
-        if val is not None:
-            cmd.append('-DPYBIND11%s="%s"' % (name[len("_PYBIND11"):], val))
-    cmd += ["-L" + torch_lib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
-            "-L" + _HERE, "-lvoxproj", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib]
-    subprocess.check_call(cmd)
-    return EXT_PATH
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.join(_HERE, "setup.py")))
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    subprocess.check_call([sys.executable, "setup.py", "-q", "build_ext", "--inplace"] + (["--force"] if force else []), cwd=_HERE)
+    return out
 
 
 def lib():
@@ -119,7 +112,23 @@ def lib():
             L.vp_project_colors.restype = ctypes.c_int
             L.vp_project_colors.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_float), ctypes.c_double, vp, ctypes.c_int,
-                                            ctypes.c_int, vp, vp, vp, ctypes.c_int64, ctypes.c_int, vp, vp]
+                                            ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, vp,
+                                            ctypes.c_size_t, vp]
+            L.vp_colors_workspace_bytes.restype = ctypes.c_size_t
+            L.vp_colors_workspace_bytes.argtypes = [ctypes.c_int64]
+            L.vp_upsample_workspace_bytes.restype = ctypes.c_size_t
+            L.vp_upsample_workspace_bytes.argtypes = [ctypes.c_int] * 4
+            L.vp_upsample_features.restype = ctypes.c_int
+            L.vp_upsample_features.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+            L.vp_voxel_coords.restype = ctypes.c_int
+            L.vp_voxel_coords.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_float), ctypes.c_float, vp, vp,
+                                          ctypes.POINTER(ctypes.c_int32), vp]
+            L.vp_scatter_occupancy.restype = ctypes.c_int
+            L.vp_scatter_occupancy.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, vp, vp, vp]
+            L.vp_aggregate_view_f16.restype = ctypes.c_int
+            L.vp_aggregate_view_f16.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int, vp]
             _lib = L
     return _lib
 
@@ -178,7 +187,7 @@ _workspaces = {}
 
 
 def get_workspace(device):
-    """The ctypes front's per-device workspace (project_features_cuda.last_workspace covers both fronts)."""
+    """The ctypes front's per-device workspace (project_features_front.last_workspace covers both fronts)."""
     key = (device.type, device.index)
     ws = _workspaces.get(key)
     if ws is None:
@@ -290,9 +299,10 @@ def workspace_status(ws, device):
 
 
 def project_colors_raw(occ_zyx, c2w, intr, grid_origin3, voxel_size, images, color_sum, hit_count, first_view=None,
-                       view_base=0):
+                       view_base=0, pixel_uv=None):
     """vp_project_colors on torch CUDA tensors: occ i32 [Z,Y,X], c2w f32 [V,4,4], intr f32 [V,4],
-    images u8 [V,H,W,3]; color_sum f32 [n_rows,3], hit_count i32 [n_rows], first_view i32 [n_rows] or None."""
+    images u8 [V,H,W,3]; color_sum f32 [n_rows,3], hit_count i32 [n_rows], first_view i32 [n_rows] or None,
+    pixel_uv i32 [V,n_rows,2] or None (receives the sampled pixel per view and voxel ID, -1 where unseen)."""
     import torch
     dev = occ_zyx.device
     assert occ_zyx.is_cuda and occ_zyx.dtype == torch.int32 and occ_zyx.is_contiguous()
@@ -302,7 +312,11 @@ def project_colors_raw(occ_zyx, c2w, intr, grid_origin3, voxel_size, images, col
     assert intr.dtype == torch.float32 and intr.is_contiguous() and intr.numel() == V * 4
     assert color_sum.dtype == torch.float32 and color_sum.is_contiguous() and hit_count.dtype == torch.int32
     n_rows = int(hit_count.shape[0])
-    status = torch.zeros(64, dtype=torch.int32, device=dev)
+    if pixel_uv is not None:
+        assert pixel_uv.dtype == torch.int32 and pixel_uv.is_contiguous() and tuple(pixel_uv.shape) == (V, n_rows, 2)
+    need = int(lib().vp_colors_workspace_bytes(n_rows))
+    scratch = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    ptr = (scratch.data_ptr() + 255) & ~255
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     Z, Y, X = occ_zyx.shape
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -310,8 +324,71 @@ def project_colors_raw(occ_zyx, c2w, intr, grid_origin3, voxel_size, images, col
         check(lib().vp_project_colors(
             occ_zyx.data_ptr(), Z, Y, X, c2w.data_ptr(), intr.data_ptr(), V, g, ctypes.c_double(float(voxel_size)),
             images.data_ptr(), int(images.shape[1]), int(images.shape[2]), color_sum.data_ptr(), hit_count.data_ptr(),
-            first_view.data_ptr() if first_view is not None else None, n_rows, int(view_base), status.data_ptr(),
-            stream))
+            first_view.data_ptr() if first_view is not None else None,
+            pixel_uv.data_ptr() if pixel_uv is not None else None, n_rows, int(view_base), ptr, need, stream))
+
+
+def upsample_features(src_chw, H, W, keep_dtype=False, out=None):
+    """vp_upsample_features: CUDA tensor [C,h,w] (float16 or float32) -> channels-last [H,W,C], float32 or (float16
+    source with ``keep_dtype``) float16.  The counterpart of prepare_tensor_data.py:119-127,152,183-185; asynchronous on
+    the current stream.  ``out``: optional destination tensor (e.g. a slot of a resident pool)."""
+    import torch
+    assert src_chw.is_cuda and src_chw.dim() == 3 and src_chw.dtype in (torch.float16, torch.float32)
+    src = src_chw.contiguous()
+    C, h, w = (int(v) for v in src.shape)
+    src16 = src.dtype == torch.float16
+    dst_dtype = torch.float16 if (keep_dtype and src16) else torch.float32
+    if out is None:
+        out = torch.empty((H, W, C), dtype=dst_dtype, device=src.device)
+    assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (H, W, C) and out.dtype == dst_dtype
+    need = int(lib().vp_upsample_workspace_bytes(C, h, w, int(src16)))
+    scratch = torch.empty(need + 256, dtype=torch.uint8, device=src.device)
+    ptr = (scratch.data_ptr() + 255) & ~255
+    stream = torch.cuda.current_stream(src.device).cuda_stream
+    with torch.cuda.device(src.device):
+        check(lib().vp_upsample_features(src.data_ptr(), int(src16), C, h, w, out.data_ptr(), int(dst_dtype == torch.float16),
+                                         int(H), int(W), ptr, need, stream))
+    return out
+
+
+def build_occupancy_device(points_xyz, grid_origin3, voxel_size):
+    """vp_voxel_coords + vp_scatter_occupancy: CUDA float32 [N,3] points -> (occ int32 [Z,Y,X] on the same device,
+    min_coord int[3] before the shift).  build_sparse_occupancy.py:30-53: half-to-even rounding in float32, the grid is
+    shifted to start at zero when any coordinate is negative, the last vertex wins on duplicates."""
+    import torch
+    assert points_xyz.is_cuda and points_xyz.dtype == torch.float32 and points_xyz.dim() == 2 and points_xyz.shape[1] == 3
+    pts = points_xyz.contiguous()
+    N = int(pts.shape[0])
+    dev = pts.device
+    coords = torch.empty((N, 3), dtype=torch.int32, device=dev)
+    scratch = torch.zeros(8, dtype=torch.int32, device=dev)
+    mm = (ctypes.c_int32 * 6)()
+    g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        check(lib().vp_voxel_coords(pts.data_ptr(), N, g, ctypes.c_float(float(voxel_size)), coords.data_ptr(),
+                                    scratch.data_ptr(), mm, stream))
+        lo, hi = [int(mm[k]) for k in range(3)], [int(mm[3 + k]) for k in range(3)]
+        shift = lo if min(lo) < 0 else [0, 0, 0]                       # BSO:36-39
+        dx, dy, dz = (hi[k] - shift[k] + 1 for k in range(3))          # BSO:40-41
+        occ = torch.empty((dz, dy, dx), dtype=torch.int32, device=dev)
+        sh = (ctypes.c_int32 * 3)(*shift)
+        check(lib().vp_scatter_occupancy(coords.data_ptr(), N, sh, dz, dy, dx, occ.data_ptr(), scratch.data_ptr(), stream))
+    return occ, lo
+
+
+def aggregate_view_f16(view_sum, view_count, run16, views, first_view, view_index, nonfinite):
+    """vp_aggregate_view_f16 (aggregate_voxel_features_onthefly.py:307-313 over the rows hit in this view; leaves
+    view_sum / view_count zeroed).  Asynchronous on the current stream."""
+    import torch
+    n_rows, C = (int(v) for v in view_sum.shape)
+    assert view_sum.dtype == torch.float32 and view_sum.is_contiguous() and view_count.dtype == torch.int32
+    assert run16.dtype == torch.float16 and run16.is_contiguous() and tuple(run16.shape) == (n_rows, C)
+    assert views.dtype == torch.int32 and first_view.dtype == torch.int32 and nonfinite.dtype == torch.int32
+    stream = torch.cuda.current_stream(view_sum.device).cuda_stream
+    with torch.cuda.device(view_sum.device):
+        check(lib().vp_aggregate_view_f16(view_sum.data_ptr(), view_count.data_ptr(), run16.data_ptr(), views.data_ptr(),
+                                          first_view.data_ptr(), int(view_index), nonfinite.data_ptr(), n_rows, C, stream))
 
 
 def stream_read_gbs(buf, repeats=3):

@@ -167,6 +167,7 @@ def main():
     from synthetic_scene import make_features_torch, make_scene
 
     n_vox, n_views, W, H, C = WORKLOADS[a.workload]
+    C = int(os.environ.get("VOXPROJ_BENCH_C", C))      # diagnostic only (row-size experiments)
     if a.views:
         n_views = a.views
     scene = make_scene(n_vox, n_views, W, H, seed=0)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 1
+#define VP_ABI_VERSION 2
 
 enum {
     VP_OK = 0,
@@ -41,7 +41,8 @@ enum {
                                 (the reference always does: K.cu:454-457)                          */
     VP_FLAG_REUSE_ACCEL = 2, /* the occupancy-derived tables in the workspace are still valid for
                                 this occupancy grid (same pointer, contents and n_rows): skip
-                                rebuilding them                                                    */
+                                rebuilding them.  VP_EINVAL if the library has not built tables on
+                                this workspace for the same (B, dims, n_rows)                       */
     VP_FLAG_EXACT_MARCH = 4, /* A/B arm: evaluate every ray sample like K.cu:47-82 does instead of
                                 leaping over provably empty space (same results, slower)           */
     VP_FLAG_PIPELINE = 8,    /* asynchronous job mode (excludes VP_FLAG_SYNC): phase 1 (ray-march) runs on a
@@ -146,8 +147,11 @@ int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const flo
                             void *stream, int flags);
 
 /*
- * Reads back and clears the device-side status word of a workspace after the stream has been
- * synchronised by the caller (for calls made without VP_FLAG_SYNC).  Returns VP_OK, VP_EBADID...
+ * Drains the workspace's streams, then reads back AND CLEARS the sticky device-side error words of the workspace:
+ * they collect the errors (out-of-range ID: VP_EBADID; a ray parameter that cannot advance: VP_EINVAL) of EVERY call
+ * made on the workspace since the previous vp_workspace_status, pipelined or not -- no later call erases them.
+ * The reference only prints device errors (K.cu:454-457, cutilCheckMsg); here they surface as a return code.
+ * Returns VP_OK when no call has reported anything.
  */
 int vp_workspace_status(void *workspace, void *stream);
 
@@ -175,25 +179,71 @@ int vp_profile_read(double *ms4, int64_t *launches4);
 /*
  * RGB path: replaces the per-voxel Python loop of DPC:54-81 plus the per-view accumulation of
  * aggregate_voxel_colors_onthefly.py:134-140 for a batch of V views (voxel-driven, nearest pixel, no
- * occlusion test, float64 arithmetic exactly as numpy promotes it there).
+ * occlusion test, float64 arithmetic exactly as numpy promotes it there).  One lane per occupied voxel.
  *
- *   occ        i32 [dimz,dimy,dimx] device, > 0 = voxel ID (BSO:44-46; DPC:50 tests occ > 0)
+ *   occ        i32 [dimz,dimy,dimx] device, > 0 = voxel ID (BSO:44-46; DPC:50 tests occ > 0).  Every ID must label
+ *              exactly ONE cell (build_sparse_occupancy.py guarantees it); a duplicate returns VP_EINVAL
  *   c2w        f32 [V,16] device, row-major camera->world (DPC:61-62 reads R and t from it)
  *   intr       f32 [V,4] device, fx fy cx cy of each view (DPC:64)
  *   images     u8  [V,img_h,img_w,3] device (DPC:52,70)
- *   color_sum  f32 [n_rows,3] in/out: += img[v,u]/255 for every view that sees the voxel (AGGC:139)
+ *   color_sum  f32 [n_rows,3] in/out: += img[v,u]/255 for every view that sees the voxel, in view order (AGGC:139)
  *   hit_count  i32 [n_rows]   in/out: += number of such views (AGGC:140)
  *   first_view i32 [n_rows]   in/out or NULL: min(view_base + v) over those views -- reproduces the
  *                             dict insertion order of AGGC:136-137 on the host
- *   status_dev i32 [64] device scratch
+ *   pixel_uv   i32 [V,n_rows,2] out or NULL: the pixel (u, v) sampled for voxel `id` in view v (DPC:76
+ *                             `pixel_indices`), (-1,-1) where the voxel is not seen
+ *   workspace  device scratch of >= vp_colors_workspace_bytes(n_rows) bytes, 256-byte aligned
  * Synchronous (returns after the stream has drained).
  */
+size_t vp_colors_workspace_bytes(int64_t n_rows);
 int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx,
                       const float *c2w, const float *intr, int V,
                       const float *grid_origin_host, double voxel_size,
                       const uint8_t *images, int img_h, int img_w,
-                      float *color_sum, int32_t *hit_count, int32_t *first_view,
-                      int64_t n_rows, int view_base, int32_t *status_dev, void *stream);
+                      float *color_sum, int32_t *hit_count, int32_t *first_view, int32_t *pixel_uv,
+                      int64_t n_rows, int view_base, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Feature-map up-sampler: replaces the 512 x cv2.resize(channel, (W,H), INTER_LINEAR) calls, the cast back to the file's
+ * dtype and the permute to channels-last of prepare_tensor_data.py:119-127,152,183-185.
+ *   src_chw   f16 or f32 [C,h,w] device (the LSeg .npy layout, script/extract_lseg_features.py:97)
+ *   dst_hwc   f32 [H,W,C] (what project_features_cuda reads) or f16 [H,W,C] (for vp_project_features_f16; f16 source only)
+ *   workspace >= vp_upsample_workspace_bytes(C,h,w,src_is_f16) bytes: the [h,w,C] transpose of the source
+ * Arithmetic = OpenCV's published INTER_LINEAR rule for CV_32F images (half-pixel centres, float32 coefficients,
+ * horizontal then vertical pass, no FMA), cast to the source dtype, widened: spelled out in csrc/vp_prep.h and restated in
+ * oracle/resize_oracle.py.  Also produces a plain copy when (H,W) == (h,w).  Asynchronous on `stream`.
+ */
+size_t vp_upsample_workspace_bytes(int C, int h, int w, int src_is_f16);
+int vp_upsample_features(const void *src_chw, int src_is_f16, int C, int h, int w,
+                         void *dst_hwc, int dst_is_f16, int H, int W,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Occupancy builder: replaces build_sparse_occupancy.py:30-53 in two steps around the one host decision (grid size):
+ *   vp_voxel_coords      coords[i] = np.round((pts[i] - origin) / voxel_size) in float32, half to even (BSO:32), written as
+ *                        i32 [N,3] (x,y,z); minmax_host[0..2] = per-axis minimum, [3..5] = maximum (BSO:35,40).  Blocking.
+ *   vp_scatter_occupancy occ[z,y,x] = i + 1 for coords[i] - shift (BSO:36-39 shifts by the minimum when any is negative),
+ *                        the LAST vertex wins on duplicates (BSO:45-46); occ i32 [dimz,dimy,dimx] is zeroed first.  Blocking.
+ *   scratch8_dev         8 ints of device scratch
+ */
+int vp_voxel_coords(const float *points_xyz, int64_t N, const float *grid_origin_host, float voxel_size,
+                    int32_t *coords, int32_t *scratch8_dev, int32_t *minmax_host, void *stream);
+int vp_scatter_occupancy(const int32_t *coords, int64_t N, const int32_t *shift3_host,
+                         int dimz, int dimy, int dimx, int32_t *occ, int32_t *scratch8_dev, void *stream);
+
+/*
+ * The aggregator's per-view accumulate in the reference's arithmetic (aggregate_voxel_features_onthefly.py:307-313 on
+ * the float16 rows of debug_project_features.py:252), over the rows hit in this view only:
+ *   view_sum   f32 [n_rows,C] in: the view's pixel sums (vp_project_features into a zeroed buffer); out: zero again
+ *   view_count i32 [n_rows]   in: the view's pixel counts; out: zero again
+ *   run16      f16 [n_rows,C] running per-voxel sum: first hit = clone of the fp16-rounded row, later hits fp16 +=
+ *   views      i32 [n_rows]   += 1 for every voxel hit in this view (AGG:313 counts VIEWS)
+ *   first_view i32 [n_rows]   = view_index where the voxel is hit for the first time (dict insertion order)
+ *   nonfinite_dev i32 [1]     |= 1 if a float16 row of this view holds NaN or Inf (AGG:303-304 prints an error)
+ * Asynchronous on `stream`.
+ */
+int vp_aggregate_view_f16(float *view_sum, int32_t *view_count, void *run16, int32_t *views, int32_t *first_view,
+                          int view_index, int32_t *nonfinite_dev, int64_t n_rows, int C, void *stream);
 
 /*
  * Forgets the side streams / events the library keeps for a workspace that was used with

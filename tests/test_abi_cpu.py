@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(voxproj_host.EXPORTS) == names
     lib.vp_abi_version.restype = ctypes.c_int
-    assert lib.vp_abi_version() == 1
+    assert lib.vp_abi_version() == 2
 
 
 def test_workspace_bytes_is_pure_host_arithmetic():
@@ -51,16 +51,18 @@ TEN = ["encoded_2d_features", "occupancy_3D", "viewMatrixInv", "intrinsicParams"
 
 @pytest.fixture(scope="module")
 def dropin():
-    """The drop-in module with its compiled pybind11 front built (hipcc as host compiler, ~1 min the first time)."""
+    """The compiled drop-in module (built by the package's setup.py, ~1 min the first time) and the Python front."""
+    import types
+
     import voxproj_host
     voxproj_host.build_ext()
-    import importlib
+    import torch  # noqa: F401  (libtorch must be loaded before the extension)
 
     import project_features_cuda as m
-    if m.IMPLEMENTATION != "compiled":      # imported before the extension existed
-        m = importlib.reload(m)
-    assert m.IMPLEMENTATION == "compiled", "project_features_cuda did not pick up _project_features_ext.so"
-    return m
+    import project_features_front as front
+    assert m.__file__ == voxproj_host.ext_path(), "project_features_cuda is not the compiled extension module"
+    return types.SimpleNamespace(project_features_cuda=m.project_features_cuda,
+                                 project_features_cuda_py=front.project_features_cuda_py, module=m)
 
 
 def test_wrapper_rejects_cpu_tensors_like_check_cuda(dropin):

@@ -27,21 +27,24 @@ FRONT = {"name": "compiled"}
 def _front(request):
     # every test runs through both fronts of the drop-in module: the compiled pybind11 wrapper
     # (csrc/project_features_ext.cpp) and the ctypes one; both end in the same C-ABI call
-    import project_features_cuda as m
     if request.param == "compiled":
-        assert m.IMPLEMENTATION == "compiled", "_project_features_ext.so is not built: run __graft_entry__.build()"
+        import project_features_cuda as m      # ModuleNotFoundError = not built: run __graft_entry__.build()
+        assert m.__file__.endswith(".so")
     FRONT["name"] = request.param
     yield request.param
 
 
 def _drop_in():
-    import project_features_cuda as m
-    return m.project_features_cuda if FRONT["name"] == "compiled" else m.project_features_cuda_py
+    if FRONT["name"] == "compiled":
+        import project_features_cuda as m
+        return m.project_features_cuda
+    import project_features_front
+    return project_features_front.project_features_cuda_py
 
 
 def _last_ws():
-    import project_features_cuda as m
-    return m.last_workspace(torch.device(DEV), front=FRONT["name"])
+    import project_features_front
+    return project_features_front.last_workspace(torch.device(DEV), front=FRONT["name"])
 
 
 def _gpu_call(feats, occ, c2w, intr, opts, origin, vs, count_t, out_t):
@@ -703,3 +706,74 @@ def test_randomized_job_mode_against_the_oracle(oracle_mod, monkeypatch):
         assert np.abs(out_t.cpu().numpy().astype(np.float64) - out64).max() <= 1e-4 * scale, case
         ws.release()
     assert saw_heavy >= 3
+
+
+def test_device_errors_of_an_early_pipelined_call_are_still_reported(oracle_mod):
+    # The status words are sticky per workspace: an out-of-range ID (or a ray that cannot advance) raised by the
+    # FIRST of five pipelined calls must still surface at workspace_status, although the two buffer sets -- and with
+    # them the per-call counters -- have been recycled twice since (the reference only prints device errors,
+    # project_image_cuda_kernel.cu:454-457).  Reading the status clears it.
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 6, 48, 32, seed=91, room=(5.0, 4.0, 2.4))
+    C = 8
+    feats_t = torch.from_numpy(make_features_np(6, 32, 48, C, seed=91)[None]).to(dev)
+    occ_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+    c2w_t = torch.from_numpy(s.c2w).to(dev)
+    intr_t = torch.from_numpy(s.intr[None]).to(dev)
+    origin = [float(v) for v in s.grid_origin]
+    good = [float(v) for v in s.opts()]
+    n_rows = s.n_vox + 1
+    vmis = [c2w_t[v:v + 1].reshape(-1).contiguous() for v in range(6)]
+
+    def run(first_opts, first_rows):
+        ws = voxproj_host.Workspace()
+        small = (torch.zeros(first_rows, dtype=torch.int32, device=dev), torch.zeros(first_rows, C, device=dev))
+        full = (torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, C, device=dev))
+        for k in range(5):
+            cnt, out = small if k == 0 else full
+            voxproj_host.project_features_raw(feats_t[:, k:k + 1], occ_t, vmis[k], intr_t, first_opts if k == 0 else good,
+                                              cnt, out, origin, s.voxel_size, workspace=ws, sync=False, pipeline=True)
+        return ws, full
+
+    ws, _ = run(good, 100)                                       # call 0: outputs far too small for IDs up to 2000
+    with pytest.raises(voxproj_host.VoxprojError, match="outside"):
+        voxproj_host.workspace_status(ws, dev)
+    voxproj_host.workspace_status(ws, dev)                       # cleared by the read: the workspace is usable again
+    bad_inc = list(good)
+    bad_inc[4] = 1e-8
+    ws, _ = run(bad_inc, n_rows)                                 # call 0: increment below half an ulp of t
+    with pytest.raises(voxproj_host.VoxprojError, match="never terminate"):
+        voxproj_host.workspace_status(ws, dev)
+    voxproj_host.workspace_status(ws, dev)
+    ws, full = run(good, n_rows)                                 # and a clean sequence reports nothing
+    voxproj_host.workspace_status(ws, dev)
+    # calls 1..4 accumulated into `full` (call 0 went into its own tensors)
+    h = oracle_mod.first_hit(s.occ[None].astype(np.int64), s.c2w[1:5].reshape(-1), s.intr[None], s.opts(), s.grid_origin,
+                             s.voxel_size, 1, 4)
+    ref = np.bincount(h.reshape(-1), minlength=n_rows).astype(np.int32) * (np.arange(n_rows) > 0)
+    assert np.array_equal(full[0].cpu().numpy(), ref)
+
+
+def test_reuse_accel_on_a_workspace_without_tables_is_refused():
+    # VP_FLAG_REUSE_ACCEL is only honoured for tables the library built on this very workspace for this grid shape
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 1, 40, 24, seed=92, room=(5.0, 4.0, 2.4))
+    feats_t = torch.from_numpy(make_features_np(1, 24, 40, 8, seed=92)[None]).to(dev)
+    occ_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+    args = (torch.from_numpy(s.c2w).reshape(-1).to(dev), torch.from_numpy(s.intr[None]).to(dev), [float(v) for v in s.opts()])
+    n_rows = s.n_vox + 1
+    cnt, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 8, device=dev)
+    tail = ([float(v) for v in s.grid_origin], s.voxel_size)
+    ws = voxproj_host.Workspace()
+    with pytest.raises(voxproj_host.VoxprojError, match="VP_FLAG_REUSE_ACCEL"):
+        voxproj_host.project_features_raw(feats_t, occ_t, *args, cnt, out, *tail, workspace=ws, reuse_accel=True)
+    voxproj_host.project_features_raw(feats_t, occ_t, *args, cnt, out, *tail, workspace=ws, reuse_accel=False)
+    single = cnt.clone()
+    assert int(single.sum()) > 0
+    voxproj_host.project_features_raw(feats_t, occ_t, *args, cnt, out, *tail, workspace=ws, reuse_accel=True)     # now fine
+    assert torch.equal(cnt, 2 * single)
+    cnt2, out2 = torch.zeros(n_rows + 7, dtype=torch.int32, device=dev), torch.zeros(n_rows + 7, 8, device=dev)
+    with pytest.raises(voxproj_host.VoxprojError, match="VP_FLAG_REUSE_ACCEL"):                                    # other n_rows
+        voxproj_host.project_features_raw(feats_t, occ_t, *args, cnt2, out2, *tail, workspace=ws, reuse_accel=True)

@@ -3,6 +3,7 @@ JSON schema, feature up-sampling contract, and the tensor_data.pt schema."""
 import json
 
 import numpy as np
+import pytest
 import torch
 
 
@@ -53,20 +54,11 @@ def test_upsample_features_contract():
     same = ptd.upsample_features(arr)                                       # no size: only the layout changes
     assert same.dtype == torch.float32 and same.shape == (h, w, C)
     assert np.array_equal(same.numpy(), arr.astype(np.float32).transpose(1, 2, 0))
-    up = ptd.upsample_features(arr, size=(12, 18))
-    assert up.shape == (12, 18, C) and up.dtype == torch.float32 and up.is_contiguous()
-    # PTD:126 casts the resized map back to fp16 before widening: every value is fp16-representable
-    assert np.array_equal(up.numpy(), up.numpy().astype(np.float16).astype(np.float32))
-    kept = ptd.upsample_features(arr, size=(12, 18), keep_dtype=True)
-    assert kept.dtype == torch.float16 and np.array_equal(kept.float().numpy(), up.numpy())
-    # bilinear with half-pixel centres: constants stay, values stay inside the range of their neighbours,
-    # and a 2x up-sample reproduces the 0.25/0.75 stencil away from the border
-    const = ptd.upsample_features(np.full((2, 4, 4), 0.5, np.float16), size=(8, 8))
-    assert (const == 0.5).all()
-    assert up.min() >= float(arr.min()) and up.max() <= float(arr.max())
-    a32 = arr.astype(np.float32)
-    exp = (0.75 * (0.75 * a32[:, 2, 3] + 0.25 * a32[:, 2, 4]) + 0.25 * (0.75 * a32[:, 3, 3] + 0.25 * a32[:, 3, 4]))
-    assert np.allclose(up.numpy()[5, 7, :], exp.astype(np.float16).astype(np.float32), atol=2e-3)
+    kept = ptd.upsample_features(arr, keep_dtype=True)
+    assert kept.dtype == torch.float16 and np.array_equal(kept.numpy(), arr.transpose(1, 2, 0))
+    # a change of size is the HIP up-sampler's job (tests/test_gpu_prep_rows.py): no CPU fallback
+    with pytest.raises(RuntimeError, match="GPU"):
+        ptd.upsample_features(arr, size=(12, 18))
 
 
 def test_prepare_tensor_data_main_writes_the_reference_schema(tmp_path):
@@ -88,10 +80,10 @@ def test_prepare_tensor_data_main_writes_the_reference_schema(tmp_path):
     out = tmp_path / "tensor_data.pt"
     ptd.main(["--lseg_dir", str(lseg), "--scaled_camera_params", str(tmp_path / "cam.json"), "--occupancy", str(tmp_path / "occ.pt"),
               "--voxel_size", "0.05", "--grid_origin", "1", "2", "3", "--max_images", "10", "--output", str(out),
-              "--image_size", "10", "14", "--downsample_factor", "0.5"])
+              "--image_size", "5", "7", "--downsample_factor", "0.5", "--device", "cpu"])     # same size: no resize, no GPU
     d = torch.load(out)
     assert set(d) == {"encoded_2d_features", "occupancy_3D", "intrinsicParams", "viewMatrixInv", "grid_origin", "voxel_size"}
-    assert d["encoded_2d_features"].shape == (1, 3, 10, 14, 4) and d["encoded_2d_features"].dtype == torch.float32
+    assert d["encoded_2d_features"].shape == (1, 3, 5, 7, 4) and d["encoded_2d_features"].dtype == torch.float32
     assert d["viewMatrixInv"].shape == (1, 3, 4, 4) and d["viewMatrixInv"].dtype == torch.float32
     # PTD:143 and :162 both append when a downsample factor is given: two intrinsics rows per view,
     # the scaled one first -- index 0 is what debug_project_features.py:146 reads
@@ -102,10 +94,48 @@ def test_prepare_tensor_data_main_writes_the_reference_schema(tmp_path):
     assert d["grid_origin"].dtype == torch.float32 and d["grid_origin"].tolist() == [1.0, 2.0, 3.0]
     # without a factor the reference still appends twice (PTD:152 and :162): two identical rows per view
     ptd.main(["--lseg_dir", str(lseg), "--scaled_camera_params", str(tmp_path / "cam.json"), "--occupancy", str(tmp_path / "occ.pt"),
-              "--voxel_size", "0.05", "--grid_origin", "1", "2", "3", "--max_images", "2", "--output", str(tmp_path / "t2.pt")])
+              "--voxel_size", "0.05", "--grid_origin", "1", "2", "3", "--max_images", "2", "--output", str(tmp_path / "t2.pt"),
+              "--device", "cpu"])
     d2 = torch.load(tmp_path / "t2.pt")
     assert d2["encoded_2d_features"].shape == (1, 2, 5, 7, 4) and d2["intrinsicParams"].shape == (1, 4, 4)
     assert d2["intrinsicParams"][0, 0].tolist() == d2["intrinsicParams"][0, 1].tolist() == [700.0, 700.0, 350.0, 250.0]
     # views follow the sorted file names (PTD:101-104), the file without a camera entry is skipped
     first = np.load(lseg / "DSC_0001.npy")
-    assert torch.equal(d["encoded_2d_features"][0, 0], ptd.upsample_features(first, (10, 14)))
+    assert torch.equal(d["encoded_2d_features"][0, 0], ptd.upsample_features(first))
+
+
+def test_prepare_tensor_data_color_writes_the_reference_schema_with_image_key(tmp_path):
+    # prepare_tensor_data_color.py:60-160: same dict as prepare_tensor_data.py plus `image` (uint8 [H,W,3], PTDC:144);
+    # the feature map is up-sampled to the IMAGE size with torch's bilinear interpolate (PTDC:101-105); intrinsics are
+    # the unscaled ones, one row per view; a view without an image file keeps its feature map's size
+    from PIL import Image
+
+    import prepare_tensor_data_color as ptdc
+    rng = np.random.default_rng(9)
+    lseg, images = tmp_path / "feats", tmp_path / "images"
+    lseg.mkdir(); images.mkdir()
+    arr = rng.standard_normal((4, 5, 7)).astype(np.float16)
+    np.save(lseg / "DSC_0001.npy", arr)
+    img = rng.integers(0, 256, (10, 14, 3), dtype=np.uint8)
+    Image.fromarray(img).save(images / "DSC_0001.png")
+    cams = {"images": {"0": {"name": "DSC_0001", "camera_id": 1, "R": _rot(rng).tolist(), "tvec": rng.standard_normal(3).tolist()}},
+            "cameras": {"1": {"params": [700.0, 710.0, 350.0, 250.0]}}}
+    (tmp_path / "cam.json").write_text(json.dumps(cams))
+    occ = torch.zeros(3, 4, 5, dtype=torch.int32)
+    occ[1, 2, 3] = 1
+    torch.save(occ, tmp_path / "occ.pt")
+    out = tmp_path / "tensor_data.pt"
+    common = ["--lseg_dir", str(lseg), "--scaled_camera_params", str(tmp_path / "cam.json"), "--occupancy", str(tmp_path / "occ.pt"),
+              "--voxel_size", "0.05", "--grid_origin", "1", "2", "3", "--max_images", "1", "--output", str(out)]
+    ptdc.main(common + ["--images_dir", str(images)])
+    d = torch.load(out, weights_only=False)
+    assert set(d) == {"encoded_2d_features", "occupancy_3D", "intrinsicParams", "viewMatrixInv", "grid_origin", "voxel_size", "image"}
+    assert isinstance(d["image"], np.ndarray) and d["image"].dtype == np.uint8 and np.array_equal(d["image"], img)
+    assert d["encoded_2d_features"].shape == (1, 1, 10, 14, 4) and d["encoded_2d_features"].dtype == torch.float32
+    exp = torch.nn.functional.interpolate(torch.from_numpy(arr)[None].float(), size=(10, 14), mode="bilinear", align_corners=False)[0]
+    assert torch.equal(d["encoded_2d_features"][0, 0], exp.permute(1, 2, 0))
+    assert d["intrinsicParams"].shape == (1, 1, 4) and d["intrinsicParams"][0, 0].tolist() == [700.0, 710.0, 350.0, 250.0]
+    assert d["viewMatrixInv"].shape == (1, 1, 4, 4) and d["voxel_size"] == 0.05
+    ptdc.main(common + ["--images_dir", str(tmp_path / "nowhere")])
+    d2 = torch.load(out, weights_only=False)
+    assert d2["encoded_2d_features"].shape == (1, 1, 5, 7, 4) and d2["image"].shape == (5, 7, 3) and not d2["image"].any()

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-semantic-segmentation_amd")]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import project_features_cuda as m  # noqa: E402
+import project_features_cuda as m  # noqa: E402  (the compiled extension)
+import project_features_front as front  # noqa: E402
 from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 
 dev = torch.device("cuda", 0)
@@ -25,9 +26,8 @@ origin = torch.from_numpy(s.grid_origin)
 count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
 out = torch.zeros(n_vox + 1, C, device=dev)
 pm = torch.tensor([False])
-print("front:", m.IMPLEMENTATION)
 for fresh in (False, True):
-    for fn, name in ((m.project_features_cuda, m.IMPLEMENTATION), (m.project_features_cuda_py, "python")):
+    for fn, name in ((m.project_features_cuda, "compiled"), (front.project_features_cuda_py, "python")):
         ts = []
         for rep in range(3):
             torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 """A/B of two builds of libvoxproj.so on the SAME feature-pool allocation (its placement moves the gather's speed by
 several per cent, so builds cannot be compared across processes): python tools/probe_ab.py libA.so libB.so [...]
 Prints mean k_gather / k_first_hit time per launch, serial phases (--pipeline: pipelined), R2 scene with 16 views per
-call (--r1: the R1 scene, 25 views per call)."""
+call (--r1: the R1 scene, 25 views per call; --f16: fp16 feature maps)."""
 import os
 import sys
 
@@ -14,6 +14,7 @@ from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 
 libs = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
 pipeline = "--pipeline" in sys.argv
+half = "--f16" in sys.argv
 dev = torch.device("cuda", 0)
 if "--r1" in sys.argv:      # BASELINE config 2
     n_vox, n_views, W, H, C = 80000, 100, 484, 274, 512
@@ -30,6 +31,8 @@ origin = [float(v) for v in s.grid_origin]
 vmis = [c2w[i * V:(i + 1) * V].reshape(-1).contiguous() for i in range(NCALL)]
 feats = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
 make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
+if half:
+    feats = feats.half()
 count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
 out = torch.zeros(n_vox + 1, C, dtype=torch.float32, device=dev)
 ref = None
