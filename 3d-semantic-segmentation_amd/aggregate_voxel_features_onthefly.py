@@ -8,6 +8,7 @@ prepare_tensor_data / debug_project_features) and then adds the per-view result 
 dtypes and row order, so stage 5 (voxel_to_gaussian/voxeltoGaussian_logits.py:40-46) reads them unchanged:
 
   ALL_nonzero_voxel_features_{n_views}_vox{N}.pt   xyz f32 [n,3], avg_feats f16 [n,C], voxel_coords i32 [n,3]   (AGG:443-451)
+  ALL_nonzero_voxels_with_features_{n_views}_vox{N}.ply   ASCII x y z + first three channels as uchar rgb        (AGG:425-440)
   checkpoint_features_{k}.pt  (every 20 views)     xyz f64, avg_feats f16, hit_count i32, voxel_coords i32      (AGG:318-352)
 
 Two modes:
@@ -62,7 +63,7 @@ class VoxelFeatureAggregator:
         self.n_rows = int(self.occ3.max().item()) + 1                     # DPF:158-159
         self.id_to_zyx = build_id_to_zyx(self.occ3)                       # DPF:35-45
         self.valid_id = self.id_to_zyx[:, 0] != -1
-        self.ws = voxproj_host.Workspace()
+        self.ws = voxproj_host.Workspace()       # device scratch is allocated by the first projector call
         self.n_seen = 0
         n, C = self.n_rows, self.C
         self.views = torch.zeros(n, dtype=torch.int32, device=self.dev)   # AGG voxel_hit_count
@@ -78,6 +79,20 @@ class VoxelFeatureAggregator:
             self.sum32 = torch.zeros(n, C, dtype=torch.float32, device=self.dev)
             self.count = torch.zeros(n, dtype=torch.int32, device=self.dev)
 
+    def reset(self):
+        """Forget every view seen so far (the occupancy grid, its derived tables and the workspace stay)."""
+        self.flush()
+        self.n_seen = 0
+        self.views.zero_()
+        if self.mode == "parity":
+            self.run16.zero_()
+            self.first_view.fill_(_NEVER)
+            self._nonfinite.zero_()
+            self._reported = 0
+        else:
+            self.sum32.zero_()
+            self.count.zero_()
+
     def _opts(self, W, H):
         return [float(W), float(H), 0.01, 10.0, float(np.float32(self.voxel_size * 0.5))]   # DPF:167-169
 
@@ -85,6 +100,8 @@ class VoxelFeatureAggregator:
         """feats f32 [V,H,W,C] on the GPU, c2w f32 [V,4,4], intr4 f32 [4] (shared by the call's views)."""
         V, H, W, C = feats.shape
         assert C == self.C
+        if self.dev.type != "cuda":
+            raise RuntimeError("VoxelFeatureAggregator.add_views projects on the GPU: there is no CPU path")
         feats = feats.contiguous()
         intr = intr4.reshape(1, 4).to(self.dev, torch.float32).contiguous()
         c2w = c2w.to(self.dev, torch.float32).contiguous()
@@ -134,14 +151,17 @@ class VoxelFeatureAggregator:
                 print(f"[STEP 3][ERROR] NaN or Inf detected in projected features for view {self._reported + v}")
             self._reported = self.n_seen
 
-    def all_reduce(self):
-        """Combine the ranks' partial {sum, count, views} (fast mode; one RCCL all-reduce each)."""
+    def all_reduce(self, dst=None):
+        """Combine the ranks' partial {sum, count, views} (fast mode): one SUM collective per tensor over RCCL.
+        ``dst=None`` all-reduces (every rank holds the scene), ``dst=0`` reduces to rank 0 only -- half the traffic, and
+        enough when rank 0 alone writes the files (main() does that).  The number of views seen is always all-reduced."""
         import torch.distributed as dist
         assert self.mode != "parity", "the parity mode is order-dependent (fp16 running sums) and stays on one GPU"
         from view_sharding import reduce_partials
         self.flush()
         n = torch.tensor([self.n_seen], device=self.dev)
-        reduce_partials(dist, [self.sum32, self.count, self.views, n])
+        reduce_partials(dist, [self.sum32, self.count, self.views], dst=dst)
+        reduce_partials(dist, [n])
         self.n_seen = int(n.item())
 
     def result(self, xyz_dtype=np.float32):
@@ -164,6 +184,30 @@ class VoxelFeatureAggregator:
         if self.mode != "parity":
             out.update(sum=self.sum32[ids].cpu(), count=self.count[ids].cpu(), voxel_ids=ids.to(torch.int32).cpu())
         return out
+
+
+def write_feature_ply(path, xyz_f32, avg_feats_f16):
+    """ALL_nonzero_voxels_with_features_*.ply (AGG:425-440): ASCII, float x y z, and -- when there are at least three
+    feature channels -- the first three, clipped to [0,1] and scaled to uchar, as red green blue (the arithmetic stays in
+    the features' own dtype, float16, as numpy does it there: np.clip(avg_feats[i,:3], 0, 1) * 255 -> astype(uint8))."""
+    xyz = np.asarray(xyz_f32, dtype=np.float32)
+    feats = np.asarray(avg_feats_f16)
+    with_rgb = feats.ndim == 2 and feats.shape[1] >= 3
+    if with_rgb:
+        with np.errstate(invalid="ignore"):
+            rgb = (np.clip(feats[:, :3], 0, 1) * 255).astype(np.uint8)
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\n")
+        f.write(f"element vertex {xyz.shape[0]}\n")
+        f.write("property float x\nproperty float y\nproperty float z\n")
+        if with_rgb:
+            f.write("property uchar red\nproperty uchar green\nproperty uchar blue\n")
+        f.write("end_header\n")
+        for i, pt in enumerate(xyz):
+            line = f"{pt[0]} {pt[1]} {pt[2]}"
+            if with_rgb:
+                line += f" {rgb[i, 0]} {rgb[i, 1]} {rgb[i, 2]}"
+            f.write(line + "\n")
 
 
 def _image_size(entry, cams, images_dir, name):
@@ -247,7 +291,9 @@ def main(argv=None):
         batch_c.append(c2w)
         batch_intr = intr
         idx = k + 1
-        if args.mode == "parity" and idx % CHECKPOINT_EVERY == 0:                                  # AGG:318-352
+        # AGG:318-352: a consolidated checkpoint every 20 views (single process: with several ranks no rank holds the
+        # scene before the final reduction, and the reference has no resume path that would read these files)
+        if world == 1 and idx % CHECKPOINT_EVERY == 0:
             agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
             batch_f, batch_c = [], []
             r = agg.result(xyz_dtype=np.float64)
@@ -262,7 +308,7 @@ def main(argv=None):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             raise RuntimeError("a rank had no usable view (fewer views with camera entries than ranks)")
-        agg.all_reduce()
+        agg.all_reduce(dst=0)             # rank 0 alone writes the files: a reduce, not an all-reduce
     elif agg is None:
         raise RuntimeError("no view could be processed")
     if rank == 0:
@@ -271,6 +317,11 @@ def main(argv=None):
         if r["xyz"].shape[0] == 0:
             print("[DONE] No occupied voxels in final aggregation, skipping export.")
         else:
+            if not torch.isfinite(r["avg_feats"].float()).all():                                          # AGG:303-304
+                print("[STEP 3][ERROR] NaN or Inf detected in the aggregated features")
+            ply_path = os.path.join(args.checkpoint_dir, f"ALL_nonzero_voxels_with_features_{n_done}_vox{num_voxels}.ply")
+            write_feature_ply(ply_path, r["xyz"].numpy(), r["avg_feats"].numpy())                        # AGG:425-440
+            print(f"[PLY] Saved nonzero voxels with features as: {ply_path}")
             save_path = os.path.join(args.checkpoint_dir, f"ALL_nonzero_voxel_features_{n_done}_vox{num_voxels}.pt")
             torch.save({"xyz": r["xyz"], "avg_feats": r["avg_feats"], "voxel_coords": r["voxel_coords"]}, save_path)   # AGG:447-451
             print(f"[PT] Saved filtered and compressed voxel data (xyz, features, coords) as: {save_path}")

@@ -145,6 +145,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     unsigned char *dist_tmp = (unsigned char *)(ws + l.dist_tmp);
     int *cnt_call = (int *)(ws + l.cnt_call[q]);
     int *heavy_list = (int *)(ws + l.heavy[q]);
+    int *work = (int *)(ws + l.work[q]);
     ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab[q]);
     int *hit = (int *)(ws + l.hit[q]);
     remember_hit(workspace, l.hit[q]);
@@ -257,22 +258,18 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
             if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
             hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
+        // the gather's work list: touched voxels by size class, largest first (needs the finished histogram)
+        hipLaunchKernelGGL(k_worklist, dim3((unsigned)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD))), dim3(256), 0, s1, (const int *)cnt_call, heavy_t,
+                           (long long)n_rows, work, status + ST_WORK0);
         sp.end();
     }
     if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
 
     // ---- phase 2 ----
-    {
-        static bool once = false;
-        if (!once) {
-            once = true;
-            const int v = getenv("VOXPROJ_F16_PLAIN") ? 1 : 0;
-            VP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_exp_plain_loads), &v, sizeof(int)));
-        }
-    }
     GatherArgs g;
     g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
+    g.work = work; g.work_n = status + ST_WORK0;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
@@ -476,7 +473,7 @@ int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx, const fl
     if (st[CST_BADID]) return fail(VP_EBADID, "an occupancy ID is outside [1, n_rows): outputs are too small for the grid's IDs");
     if (st[CST_DUP]) return fail(VP_EINVAL, "an occupancy ID labels more than one cell: the colour path needs unique IDs "
                                             "(build_sparse_occupancy.py:44-46 produces them)");
-    hipLaunchKernelGGL(k_project_colors, dim3((unsigned)((n_rows - 1 + 255) / 256)), dim3(256), 0, stream, (const int *)cell_of_id,
+    hipLaunchKernelGGL(k_project_colors, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const int *)cell_of_id,
                        dimy, dimx, c2w, intr, V, grid_origin_host[0], grid_origin_host[1], grid_origin_host[2],
                        voxel_size, (const unsigned char *)images, img_h, img_w, color_sum, (int *)hit_count,
                        (int *)first_view, (int *)pixel_uv, (long long)n_rows, view_base);

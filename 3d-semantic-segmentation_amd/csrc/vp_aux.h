@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ 
     __shared__ float lut[256];
     lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);                                                    // DPC:70,75
     __syncthreads();
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_rows) return;
-    const int cell = cell_of_id[id];
+    const int cell = id > 0 ? cell_of_id[id] : -1;        // row 0 is the dummy of the 1-based IDs
     if (cell < 0) {
         if (pixel_uv)
             for (int v = 0; v < V; v++) {

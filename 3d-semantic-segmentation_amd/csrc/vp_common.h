@@ -164,8 +164,10 @@ struct Params {
 // on the set, read by vp_workspace_counters.  ST_STICKY_* live in the block of set 0 only, are raised together with
 // their per-call twins, survive every later call on the workspace and are cleared by vp_workspace_status alone --
 // so an error raised by pipelined call j is still there when the job finally asks, however many calls later.
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5, ST_CALL_WORDS = 8,
-       ST_STICKY_BADID = 8, ST_STICKY_STUCK = 9, ST_WORDS = 64 };
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5,
+       ST_WORK0 = 16, WORK_CLASSES = 8,        // per-call: number of voxels in each size class of the gather's work list
+       ST_CALL_WORDS = 32,
+       ST_STICKY_BADID = 62, ST_STICKY_STUCK = 63, ST_WORDS = 64 };
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
@@ -182,7 +184,7 @@ struct ViewEntry {
 struct Layout {
     size_t cell_of_id, mask64, near2, dist, dist_tmp;    // occupancy-derived tables (shared)
     size_t occ_copy;                                     // (int)occupancy the tables were built from (VP_FLAG_VERIFY_ACCEL)
-    size_t status[2], cnt_call[2], heavy[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
+    size_t status[2], cnt_call[2], heavy[2], work[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
     size_t total;
     int nbx, nby, nbz;
     long long nblk;   // occupancy blocks (4x4x4 cells) per batch
@@ -211,6 +213,7 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
     for (int q = 0; q < 2; q++) {
         l.cnt_call[q] = off; off += align256(size_t(n_rows) * sizeof(int));
         l.heavy[q] = off;    off += align256(size_t(n_rows) * sizeof(int));
+        l.work[q] = off;     off += align256(size_t(WORK_CLASSES) * size_t(n_rows) * sizeof(int));
     }
     const size_t per_set = align256(size_t(B) * V * sizeof(ViewEntry)) + align256(size_t(B) * V * H * W * sizeof(int));
     size_t half = per_set;

@@ -7,8 +7,6 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // phase 2: one wavefront per voxel
 // ------------------------------------------------------------------------------------------------
-__device__ int g_exp_plain_loads = 0;   // EXPERIMENT (fp16 gather): 1 = plain instead of non-temporal row loads
-
 template <int K, int VEC>
 struct Acc {
     float a[K * VEC];
@@ -81,8 +79,7 @@ __device__ __forceinline__ void scan_box(const float *__restrict__ fv, const int
                             for (int k = 0; k < K; k++) {
                                 const int ch = (k * 64 + lane) * 8;
                                 if (cb + ch < C)
-                                    r[j][k] = g_exp_plain_loads ? *reinterpret_cast<const v8h_ *>(reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2)
-                                                                : __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
+                                    r[j][k] = __builtin_nontemporal_load(reinterpret_cast<const v8h_ *>(
                                         reinterpret_cast<const char *>(fv) + (off[j] + ch) * 2));
                                 else
                                     r[j][k] = (v8h_)(_Float16)0;
@@ -221,6 +218,8 @@ struct GatherArgs {
     const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
     const int *n_heavy;
     int heavy_t;
+    const int *work;         // work list of this call: WORK_CLASSES arrays of n_rows voxel IDs, by size class (k_worklist)
+    const int *work_n;       // voxels per class
     int *count;
     int *views_hit;          // nullable: += number of views of this call in which the voxel got >= 1 pixel
     float *out;
@@ -502,6 +501,44 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
     return true;
 }
 
+// Work list of a call: the voxels that received pixels (and are not heavy), binned by size class -- class k holds the
+// voxels with floor(log2(pixels)) == k + 3 (clamped to 0 .. WORK_CLASSES-1).  k_gather walks the classes from the largest
+// down, so the long voxels start first and the short ones fill the tail (longest-processing-time-first), and no
+// wavefront is launched for the voxels the call did not touch at all.  Inside a class the IDs keep roughly their
+// ascending order (neighbouring voxels read neighbouring pixels).  One lane per ID, appends aggregated per wavefront.
+constexpr int WL_PER_THREAD = 16;   // IDs per lane of k_worklist: a 256-thread workgroup bins 4096 voxel IDs
+
+__global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, long long n_rows,
+                                                  int *__restrict__ work, int *work_n)
+{
+    // Appends are aggregated per WORKGROUP through LDS: a handful of global atomics per 4096 IDs.  (Returning integer
+    // atomics on a few hot addresses are exactly what slows a concurrently running gather -- DESIGN.md section 2.)
+    __shared__ int n_cls[WORK_CLASSES], base_cls[WORK_CLASSES];
+    if (threadIdx.x < WORK_CLASSES) n_cls[threadIdx.x] = 0;
+    __syncthreads();
+    const long long id0 = (long long)blockIdx.x * (256 * WL_PER_THREAD);
+    int cls[WL_PER_THREAD], rank[WL_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < WL_PER_THREAD; j++) {
+        // consecutive lanes take consecutive IDs, so the ranks inside a class follow the ID order closely
+        const long long id = id0 + (long long)j * 256 + threadIdx.x;
+        int c = 0;
+        if (id > 0 && id < n_rows) c = cnt_call[id];
+        cls[j] = (c > 0 && c <= heavy_t) ? min(WORK_CLASSES - 1, max(0, 28 - __builtin_clz(c))) : -1;     // floor(log2 c) - 3
+        rank[j] = cls[j] >= 0 ? atomicAdd(&n_cls[cls[j]], 1) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < WORK_CLASSES) {
+        const int n = n_cls[threadIdx.x];
+        base_cls[threadIdx.x] = n > 0 ? atomicAdd(&work_n[threadIdx.x], n) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WL_PER_THREAD; j++)
+        if (cls[j] >= 0)
+            work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
+}
+
 template <int K, int VEC, int U>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
@@ -510,11 +547,16 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     // march waves of the next call that share the SIMD in pipelined mode.
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
-    const long long idl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
-    if (idl >= p.n_rows) return;
-    const int id = (int)idl;
+    long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int id = 0;
+#pragma unroll
+    for (int k = WORK_CLASSES - 1; k >= 0; k--) {
+        const int n = g.work_n[k];
+        if (id == 0 && w < n) id = g.work[(long long)k * p.n_rows + w];
+        w -= n;
+    }
+    if (id == 0) return;
     const int expected = g.cnt_call[id];
-    if (expected == 0 || expected > g.heavy_t) return;
     gather_voxel_wave<K, VEC, U, VP_GATHER_G(VEC)>(g, p, id, expected, lane);
 }
 

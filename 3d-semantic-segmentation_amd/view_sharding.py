@@ -14,8 +14,19 @@ def views_of_rank(n_views, rank, world):
     return list(range(rank, n_views, world))
 
 
-def reduce_partials(dist, tensors):
-    """In-place SUM all-reduce of each tensor (RCCL on GPUs, gloo in the CPU tests)."""
+def reduce_partials(dist, tensors, dst=None, async_op=False):
+    """In-place SUM reduction of each tensor over all ranks (RCCL on GPUs, gloo in the CPU tests).
+
+    ``dst=None``: all-reduce -- every rank ends up with the scene totals (what BASELINE.json's north_star words).
+    ``dst=r``:    reduce to rank r only -- half the xGMI traffic of an all-reduce; the right collective when one rank
+                  writes the scene's files; the other ranks' buffers are left in an unspecified state.
+    Integer tensors (pixel and view counts) are reduced as integers, so they stay bit-exact.  Returns the list of work
+    handles when ``async_op`` (wait on all of them before touching the tensors), else the tensors."""
+    works = []
     for t in tensors:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return tensors
+        if dst is None:
+            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+        else:
+            w = dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)
+        works.append(w)
+    return works if async_op else tensors

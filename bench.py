@@ -50,7 +50,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="R2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["R4"],
+                    help="R2 (default) = BASELINE metric config; R1 = config 2; S0 = config 1; R4 = config 5, the RGB path "
+                         "(500k voxels x 1000 views, uint8 images; its own kernel, no HBM-roofline claim)")
+    ap.add_argument("--entry", default=None, choices=("parity", "fast"),
+                    help="time the named entry point's in-process aggregation (VoxelFeatureAggregator.add_views over every "
+                         "view of the workload, features resident) instead of raw C-ABI calls; default workload R1")
+    ap.add_argument("--collective", default="reduce", choices=("reduce", "allreduce"),
+                    help="multi-GPU: how the per-rank {sum,count} are combined each pass.  reduce (default) = to rank 0 only, "
+                         "half the xGMI traffic, enough when one rank writes the scene; allreduce = every rank gets the scene")
     ap.add_argument("--chunk", type=int, default=32, help="views per vp_project_features call")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
@@ -62,28 +70,45 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--pool-tries", type=int, default=5,
-                    help="allocate the resident feature pool and the output rows this many times and keep the placement "
-                         "with the fastest pass (untimed set-up; every try is reported in the JSON line); 1 = take the "
-                         "first allocation as it comes")
+    ap.add_argument("--pool-tries", type=int, default=1,
+                    help="1 (default) = take the first allocation of the resident feature pool and the output rows as it "
+                         "comes; N > 1 = opt-in placement search: allocate N times during the untimed set-up, keep the "
+                         "placement with the fastest pass (every try is reported in the JSON line)")
     ap.add_argument("--no-overlap-reduce", action="store_true",
                     help="multi-GPU: wait for each pass's all-reduce before starting the next pass (default: the "
                          "all-reduce of pass k runs on RCCL's stream while pass k+1 is projected into a second buffer)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "R1" if a.entry else "R2"
+    return a
 
 
-def pmc_traffic(workload, chunk):
-    """HBM bytes per k_gather launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json),
+def source_digest():
+    """sha256 over the library's sources: a PMC profile only describes the kernels it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(PKG, "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip")) or name == "Makefile":
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, chunk, dtype):
+    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json),
     corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
-    Returned per VIEW of a full launch (the caller scales by its average views per launch); None unless the
-    profile was taken on this workload / views-per-call."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    None unless the profile was taken on this workload / views-per-call / dtype AND with these very kernel sources
+    (the file records the digest of csrc/ it was measured on: a stale profile yields null, not a wrong number)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
             prof = json.load(f)
     except OSError:
         return None
-    if prof.get("workload") != workload or prof.get("views_per_call") != chunk:
+    if (prof.get("workload"), prof.get("views_per_call"), prof.get("dtype")) != (workload, chunk, dtype):
+        return None
+    if prof.get("source_digest") != source_digest():
         return None
     g = prof["k_gather"]
     return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / prof["views_per_call"]
@@ -144,6 +169,214 @@ def cpu_torch_loop(scene, n_views, n_threads):
                 sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {inb} centres in bounds")
 
 
+def _barrier(dist, dev):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+
+def _max_over_ranks(dist, dt, dev):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bench_colors(a, dev, rank, world, dist):
+    """BASELINE config 5 (R4): the RGB path -- 500 000 voxels x 1000 views, uint8 [1168,1752,3] images, voxel-driven nearest
+    pixel, no occlusion (debug_project_colors.py:54-81 + aggregate_voxel_colors_onthefly.py:134-140).  One STEP = all 1000
+    views through vp_project_colors in calls of --chunk views (a pool of distinct images is cycled).  Three bytes are
+    gathered per voxel-view, so the kernel is latency / float64-ALU bound: the line carries the roofline object the
+    contract asks for, with the honest fraction, and makes no roofline claim."""
+    import voxproj_host
+    from synthetic_scene import make_scene
+    from view_sharding import reduce_partials, views_of_rank
+    N, V, W, H = 500000, a.views or 1000, 1752, 1168
+    s = make_scene(N, V, W, H, seed=0)
+    my_views = views_of_rank(V, rank, world)
+    chunk = max(1, min(a.chunk if a.chunk != 32 else 64, len(my_views)))
+    pool = chunk
+    occ = torch.from_numpy(s.occ).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    imgs = torch.randint(0, 256, (pool, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
+    c2w = torch.from_numpy(s.c2w).to(dev)
+    intr = torch.from_numpy(s.intr)[None].repeat(V, 1).to(dev).contiguous()
+    csum = torch.zeros(N + 1, 3, device=dev)
+    hits = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+    first = torch.full((N + 1,), 2 ** 30, dtype=torch.int32, device=dev)
+    origin = [float(v) for v in s.grid_origin]
+    calls = [my_views[i:i + chunk] for i in range(0, len(my_views), chunk)]
+    c2ws = [c2w[vs].contiguous() for vs in calls]
+    intrs = [intr[vs].contiguous() for vs in calls]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in calls]
+
+    def step(timed=False):
+        csum.zero_(); hits.zero_()
+        for ci, vs in enumerate(calls):
+            if timed:
+                ev[ci][0].record()
+            voxproj_host.project_colors_raw(occ, c2ws[ci], intrs[ci], origin, s.voxel_size, imgs[:len(vs)], csum, hits,
+                                            first_view=first, view_base=vs[0])
+            if timed:
+                ev[ci][1].record()
+        if dist is not None:
+            reduce_partials(dist, [csum, hits], dst=0 if a.collective == "reduce" else None)
+
+    for _ in range(max(1, a.warmup)):
+        step()
+    _barrier(dist, dev)
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(timed=(k == a.steps - 1))
+    _barrier(dist, dev)
+    dt = _max_over_ranks(dist, time.perf_counter() - t0, dev)
+    seen = torch.tensor([int(hits.sum().item()) if (dist is None or rank == 0 or a.collective == "allreduce") else 0], device=dev)
+    call_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+    if rank == 0:
+        n_seen = int(seen.item())
+        per_call_hits = n_seen / max(1, len(calls) * world)
+        # algorithmic bytes of one call: 3 B per sampled pixel, the ID->cell table build (one pass over the dense grid),
+        # 4 B cell index + read-modify-write of {3 floats, count, first view} per voxel, pose + intrinsics per view
+        algo = per_call_hits * 3 + occ.numel() * 4 + (N + 1) * (4 + 2 * 20) + chunk * 80
+        ach = algo / (call_ms * 1e-3) / 1e9
+        res = {"metric": "Mvoxel-views/sec", "value": round(N * V / (dt / a.steps) / 1e6, 1), "unit": "Mvoxel-views/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 projection, f32 colour sums",
+               "data": "synthetic",
+               "config": {"workload": f"R4: {N} voxels x {V} views x {W}x{H}x3 uint8 images, DPC semantics (nearest pixel, no "
+                                      f"occlusion), room-shell scene seed 0", "views_per_call": chunk, "resident_images": pool,
+                          "parallelism": f"views r::{world} per GPU + one RCCL {a.collective} of colour sums/counts per pass" if world > 1 else "single GPU"},
+               "voxel_view_hits_per_step": n_seen,
+               "roofline": {"bound": "hbm", "kernel": "vp_project_colors (k_color_cells + k_project_colors)", "achieved": round(ach, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                            "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4),
+                            "note": "3 bytes gathered per voxel-view after ~60 float64 operations: latency / fp64-ALU bound, "
+                                    "no HBM-roofline claim (SURVEY 8d)"}}
+        if not a.no_cpu_baseline and world == 1:
+            from oracle import oracle
+            nv = min(4, V)
+            img_np = imgs[0].cpu().numpy()
+            t1 = time.perf_counter()
+            for v in range(nv):
+                oracle.rgb_project(s.occ, s.c2w[v], s.intr, s.grid_origin, s.voxel_size, img_np)
+            dtc = time.perf_counter() - t1
+            res["cpu_baseline"] = dict(value=round(N * nv / dtc / 1e6, 3), unit="Mvoxel-views/s", cores=1, kind="port",
+                                       sample=f"{nv} of the workload's views, all {N} voxels, {dtc:.1f} s wall "
+                                              "(oracle_rgb_project: scalar C restatement of debug_project_colors.py:54-81)")
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_entry(a, dev, rank, world, dist):
+    """The named entry point measured in-process: one STEP = every view of the workload through
+    VoxelFeatureAggregator.add_views (aggregate_voxel_features_onthefly.py) with the feature maps resident, then flush().
+    parity: one view per projector call + the fp16 per-view accumulate of the reference (AGG:307-313); fast: 8 views per
+    pipelined call, fp32 sums.  Reported beside it, same run and data: the drop-in module called the way the reference
+    calls it (one view per blocking project_features_cuda call, debug_project_features.py:201-208)."""
+    import voxproj_host
+    from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
+    from synthetic_scene import make_features_torch, make_scene
+    from view_sharding import views_of_rank
+    n_vox, n_views, W, H, C = WORKLOADS[a.workload]
+    if a.views:
+        n_views = a.views
+    s = make_scene(n_vox, n_views, W, H, seed=0)
+    my_views = views_of_rank(n_views, rank, world)
+    pool = min(a.pool if a.pool != 32 else 128, len(my_views))
+    feats = torch.empty((pool, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(pool, H, W, C, dev, seed=0, out=feats)
+    c2w = torch.from_numpy(s.c2w).to(dev)
+    intr4 = torch.from_numpy(s.intr)
+    agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, C, a.entry, dev)
+    per_call = 1 if a.entry == "parity" else max(1, min(8, a.chunk))
+    calls = [my_views[i:i + per_call] for i in range(0, len(my_views), per_call)]
+
+    def step():
+        agg.reset()
+        for vs in calls:
+            slot = vs[0] % pool if (vs[0] % pool) + len(vs) <= pool else 0
+            agg.add_views(feats[slot:slot + len(vs)], c2w[vs], intr4)
+        if dist is not None:
+            agg.all_reduce(dst=0 if a.collective == "reduce" else None)
+        else:
+            agg.flush()
+
+    # untimed pre-pass through the raw C-ABI: algorithmic bytes of the dominant kernel for exactly these calls
+    occ64 = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
+    cnt = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
+    out = torch.zeros(n_vox + 1, C, device=dev)
+    intr_d = torch.from_numpy(s.intr[None]).to(dev)
+    ws0 = voxproj_host.Workspace()
+    algo = 0
+    for ci, vs in enumerate(calls):
+        slot = vs[0] % pool if (vs[0] % pool) + len(vs) <= pool else 0
+        cnt.zero_()
+        voxproj_host.project_features_raw(feats[slot:slot + len(vs)][None], occ64, c2w[vs].reshape(-1).contiguous(), intr_d,
+                                          [float(v) for v in s.opts()], cnt, out, [float(v) for v in s.grid_origin],
+                                          s.voxel_size, workspace=ws0, sync=True, reuse_accel=(ci > 0 or None))
+        ph, nt = int(cnt.sum().item()), int((cnt > 0).sum().item())
+        algo += ph * C * 4 + nt * C * 4 * 2 + len(vs) * H * W * 4 + (n_vox + 1) * 4 * 2
+    ws0.release()
+    del ws0, out
+    step()                                                     # builds the aggregator's tables, sizes its workspace
+    for _ in range(a.warmup):
+        step()
+    _barrier(dist, dev)
+    voxproj_host.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    _barrier(dist, dev)
+    dt = _max_over_ranks(dist, time.perf_counter() - t0, dev)
+    prof = voxproj_host.profile_read()
+    voxproj_host.profile_enable(False)
+    if rank == 0:
+        r = agg.result()
+        n_out = int(r["xyz"].shape[0])
+        # the drop-in module, one view per blocking call, same maps (compiled front; DPF:141-208 call pattern)
+        import project_features_cuda as dropin
+        out = torch.zeros(n_vox + 1, C, device=dev)
+        opts = torch.from_numpy(s.opts()); org = torch.from_numpy(s.grid_origin); pm = torch.tensor([False])
+        nv = min(32, len(my_views))
+        vm = [c2w[v].reshape(-1).contiguous() for v in my_views[:nv]]
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for k in range(nv):
+                dropin.project_features_cuda(feats[k % pool][None, None], occ64, vm[k], intr_d, opts, cnt, out, pm, org, s.voxel_size)
+            d1 = (time.perf_counter() - t1) / nv
+            best = d1 if best is None else min(best, d1)
+        ms_view = dt / a.steps / len(my_views) * 1e3
+        launches = max(prof["gather_launches"], 1)
+        gather_ms = prof["gather_ms"] / launches
+        res = {"metric": "Mvoxel-views/sec", "value": round(n_vox * n_views / (dt / a.steps) / 1e6, 3), "unit": "Mvoxel-views/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{a.workload} through the entry point's aggregator, --mode {a.entry}: {n_vox} voxels x {n_views} "
+                                      f"views x {W}x{H}x{C} fp32 feature maps resident, room-shell scene seed 0",
+                          "views_per_call": per_call, "resident_feature_maps": pool,
+                          "parallelism": f"views r::{world} per GPU + RCCL {a.collective}" if world > 1 else "single GPU"},
+               "entry": {"mode": a.entry, "ms_per_view": round(ms_view, 4), "rows_out": n_out,
+                         "dropin_ms_per_view": round(best * 1e3, 4), "entry_over_dropin": round(ms_view / (best * 1e3), 3),
+                         "dropin_what": "project_features_cuda (compiled module), one view per blocking call"},
+               "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3), "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
+                                     "gather": round(prof["gather_ms"] / a.steps, 3), "gather_heavy": round(prof["heavy_ms"] / a.steps, 3)},
+               "roofline": {"bound": "hbm", "kernel": "k_gather", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                            "avg_launch_ms": round(gather_ms, 4)}}
+        ach = algo / len(calls) / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
+        res["roofline"].update(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4), bytes_per_launch=int(algo / len(calls)))
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(s, C, min(a.cpu_views, n_views), host_cores())
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -166,8 +399,11 @@ def main():
     import voxproj_host
     from synthetic_scene import make_features_torch, make_scene
 
+    if a.workload == "R4":
+        return bench_colors(a, dev, rank, world, dist)
+    if a.entry:
+        return bench_entry(a, dev, rank, world, dist)
     n_vox, n_views, W, H, C = WORKLOADS[a.workload]
-    C = int(os.environ.get("VOXPROJ_BENCH_C", C))      # diagnostic only (row-size experiments)
     if a.views:
         n_views = a.views
     scene = make_scene(n_vox, n_views, W, H, seed=0)
@@ -272,10 +508,11 @@ def main():
         for ci in range(len(calls)):
             one_call(ci, o=o, c=c)
         if dist is not None:
+            dst = 0 if a.collective == "reduce" else None
             if a.no_overlap_reduce:
-                reduce_partials(dist, [o, c])
+                reduce_partials(dist, [o, c], dst=dst)
             else:
-                inflight[i] = [dist.all_reduce(o, async_op=True), dist.all_reduce(c, async_op=True)]
+                inflight[i] = reduce_partials(dist, [o, c], dst=dst, async_op=True)
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px, heavy_px = 0, 0, 0, {}, 0, 0
@@ -337,12 +574,18 @@ def main():
             torch.cuda.synchronize(dev)
             placement["ms_per_pass_after_timed_region"] = round((time.perf_counter() - t1) * 1e3, 3)
     if dist is not None and not os.environ.get("VOXPROJ_BENCH_NOVERIFY"):
-        # the buffer reduced last holds the whole scene on every rank: its hit-count total must equal the sum of the
-        # ranks' own (pre-pass) totals, exactly
+        # the buffer reduced last holds the whole scene (on rank 0 after a reduce, everywhere after an all-reduce):
+        # its hit counts must add up EXACTLY to the ranks' own (pre-pass) totals, and its feature sums, channel by
+        # channel, to the sum of the ranks' pre-pass checksums (float64) within fp32 summation rounding
         t = torch.tensor([hit_px], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        last_c = bufs[(state["k"] - 1) % len(bufs)][1]
-        assert int(last_c.sum().item()) == int(t.item()), "all-reduced hit counts do not add up to the ranks' totals"
+        chk = torch.stack([ref_checksum, ref_abs])
+        dist.all_reduce(chk)
+        last_o, last_c = bufs[(state["k"] - 1) % len(bufs)]
+        if rank == 0 or a.collective == "allreduce":
+            assert int(last_c.sum().item()) == int(t.item()), "reduced hit counts do not add up to the ranks' totals"
+            assert ((last_o.double().sum(0) - chk[0]).abs() <= 1e-6 * chk[1] + 1e-9).all(), \
+                "reduced feature sums differ from the sum of the ranks' single-rank results"
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,7 +614,7 @@ def main():
             "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} {'fp32' if a.dtype == 'f32' else 'fp16'} feature maps, "
                                    f"room-shell scene seed 0, dmin 0.01 dmax 10 step 0.5*voxel",
                        "views_per_call": chunk, "resident_feature_maps": pool,
-                       "parallelism": (f"views r::{world} per GPU + one RCCL all-reduce of sum/count per pass"
+                       "parallelism": (f"views r::{world} per GPU + one RCCL {'reduce to rank 0' if a.collective == 'reduce' else 'all-reduce'} of sum/count per pass"
                                        + ("" if a.no_overlap_reduce else ", overlapped with the next pass (two output buffers)"))
                        if world > 1 else "single GPU"},
             "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
@@ -386,8 +629,8 @@ def main():
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "measured_stream_read_gbs": round(stream_gbs, 1),
                          "frac_of_measured_stream_read": round(ach / stream_gbs, 4) if stream_gbs > 0 else None,
-                         "traffic": (int(pmc_traffic(a.workload, chunk) * len(my_views) / len(calls))
-                                     if (not a.views and world == 1 and a.dtype == "f32" and pmc_traffic(a.workload, chunk)) else None),
+                         "traffic": (int(pmc_traffic(a.workload, chunk, a.dtype) * len(my_views) / len(calls))
+                                     if (not a.views and world == 1 and pmc_traffic(a.workload, chunk, a.dtype)) else None),
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)

@@ -195,7 +195,8 @@ def dpf_select_outputs(occ_zyx, count, sums):
     idx = id_to_zyx[hit_ids].astype(np.int32)
     feats = np.asarray(sums)[hit_ids]
     valid = idx[:, 0] != -1
-    return feats[valid].astype(np.float16), idx[valid]
+    with np.errstate(over="ignore"):                       # sums beyond 65504 become inf, as torch's .to(float16) makes them
+        return feats[valid].astype(np.float16), idx[valid]
 
 
 def aggregate_views(per_view_outputs, grid_origin, voxel_size):

@@ -47,5 +47,56 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
-    assert "all-reduce" in d["config"]["parallelism"]
+    assert "reduce to rank 0" in d["config"]["parallelism"]
     assert d["hit_pixels_per_step"] > 0 and d["value"] > 0
+
+
+def test_bench_two_ranks_allreduce_variant():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
+                        "--single-device", "--collective", "allreduce", "--no-overlap-reduce"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]          # bench verifies reduced counts exactly and sums against the ranks' own
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and "all-reduce" in d["config"]["parallelism"]
+
+
+def _check_common(d):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+
+
+def test_bench_config2_r1_leg():
+    # BASELINE config 2 at its own shape (80k voxels, 484x274x512), a 12-view slice of it to keep the test short
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--views", "12", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    _check_common(d)
+    assert d["config"]["workload"].startswith("R1: 80000 voxels x 12 views x 484x274x512") and d["box_miss_voxels"] == 0
+
+
+def test_bench_config5_rgb_leg():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R4", "--views", "16", "--chunk", "8",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    _check_common(d)
+    assert d["config"]["workload"].startswith("R4: 500000 voxels x 16 views") and d["voxel_view_hits_per_step"] > 500000
+
+
+@pytest.mark.parametrize("mode", ["parity", "fast"])
+def test_bench_entry_point_leg(mode):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--entry", mode, "--views", "10", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    _check_common(d)
+    e = d["entry"]
+    assert e["mode"] == mode and e["ms_per_view"] > 0 and e["dropin_ms_per_view"] > 0 and e["rows_out"] > 1000
+    assert "R1 through the entry point" in d["config"]["workload"]

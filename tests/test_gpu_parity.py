@@ -726,27 +726,30 @@ def test_device_errors_of_an_early_pipelined_call_are_still_reported(oracle_mod)
     n_rows = s.n_vox + 1
     vmis = [c2w_t[v:v + 1].reshape(-1).contiguous() for v in range(6)]
 
-    def run(first_opts, first_rows):
+    occ_bad = occ_t + (occ_t > 0) * 5000                         # every ID beyond the outputs' rows
+
+    def run(first_opts, first_occ):
         ws = voxproj_host.Workspace()
-        small = (torch.zeros(first_rows, dtype=torch.int32, device=dev), torch.zeros(first_rows, C, device=dev))
+        own = (torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, C, device=dev))
         full = (torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, C, device=dev))
         for k in range(5):
-            cnt, out = small if k == 0 else full
-            voxproj_host.project_features_raw(feats_t[:, k:k + 1], occ_t, vmis[k], intr_t, first_opts if k == 0 else good,
-                                              cnt, out, origin, s.voxel_size, workspace=ws, sync=False, pipeline=True)
+            cnt, out = own if k == 0 else full
+            voxproj_host.project_features_raw(feats_t[:, k:k + 1], first_occ if k == 0 else occ_t, vmis[k], intr_t,
+                                              first_opts if k == 0 else good, cnt, out, origin, s.voxel_size, workspace=ws,
+                                              sync=False, pipeline=True)
         return ws, full
 
-    ws, _ = run(good, 100)                                       # call 0: outputs far too small for IDs up to 2000
+    ws, _ = run(good, occ_bad)                                   # call 0: a grid whose IDs the outputs have no rows for
     with pytest.raises(voxproj_host.VoxprojError, match="outside"):
         voxproj_host.workspace_status(ws, dev)
     voxproj_host.workspace_status(ws, dev)                       # cleared by the read: the workspace is usable again
     bad_inc = list(good)
     bad_inc[4] = 1e-8
-    ws, _ = run(bad_inc, n_rows)                                 # call 0: increment below half an ulp of t
+    ws, _ = run(bad_inc, occ_t)                                  # call 0: increment below half an ulp of t
     with pytest.raises(voxproj_host.VoxprojError, match="never terminate"):
         voxproj_host.workspace_status(ws, dev)
     voxproj_host.workspace_status(ws, dev)
-    ws, full = run(good, n_rows)                                 # and a clean sequence reports nothing
+    ws, full = run(good, occ_t)                                  # and a clean sequence reports nothing
     voxproj_host.workspace_status(ws, dev)
     # calls 1..4 accumulated into `full` (call 0 went into its own tensors)
     h = oracle_mod.first_hit(s.occ[None].astype(np.int64), s.c2w[1:5].reshape(-1), s.intr[None], s.opts(), s.grid_origin,

@@ -1,6 +1,9 @@
-"""N > 1 path on CPU: world_size-2 gloo processes shard the views (r::G), each projects its shard (the oracle
-stands in for the per-rank projector here -- tests may use it), one SUM all-reduce of {sum, count, views}
-combines them; the result must equal the single-rank result (counts exactly, sums to fp32 rounding)."""
+"""N > 1 path on CPU: world_size-2 gloo processes shard the views (r::G) and run the REAL scene-combination code of the
+entry point -- VoxelFeatureAggregator.all_reduce (all-reduce and reduce-to-rank-0 forms) and .result() -- on per-rank
+partial {sum, count, views} tensors.  Only the projection itself is stood in for (there is no GPU here; tests may use the
+oracle for that): each rank writes the oracle's per-view sums into its aggregator's state exactly where the projector's
+gather would have accumulated them.  The combined result must equal the single-rank result: counts and view counts
+exactly, sums to fp32 rounding, and the output rows (voxel order, coordinates, fp16 means) of result() likewise."""
 import os
 import sys
 
@@ -29,23 +32,45 @@ def _project(oracle, s, feats, views, count, sums, nviews):
         nviews += c1 > 0
 
 
+def _filled_aggregator(oracle, s, feats, views):
+    """A fast-mode VoxelFeatureAggregator (CPU tensors) whose state holds what projecting `views` leaves there."""
+    from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
+    agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, 8, "fast", "cpu")
+    n_rows = s.n_vox + 1
+    assert agg.n_rows == n_rows
+    count, sums, nviews = np.zeros(n_rows, np.int32), np.zeros((n_rows, 8), np.float32), np.zeros(n_rows, np.int32)
+    _project(oracle, s, feats, views, count, sums, nviews)
+    agg.sum32.copy_(torch.from_numpy(sums))
+    agg.count.copy_(torch.from_numpy(count))
+    agg.views.copy_(torch.from_numpy(nviews))
+    agg.n_seen = len(list(views))
+    return agg
+
+
 def _worker(rank, world, port, out_path):
     for p in (ROOT, PKG):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
-    from view_sharding import reduce_partials, views_of_rank
+    from view_sharding import views_of_rank
     s, feats = _scene()
-    n_rows = s.n_vox + 1
-    count, sums, nviews = np.zeros(n_rows, np.int32), np.zeros((n_rows, 8), np.float32), np.zeros(n_rows, np.int32)
     mine = views_of_rank(s.n_views, rank, world)
     assert mine == list(range(rank, 7, world))
-    _project(oracle, s, feats, mine, count, sums, nviews)
-    t = [torch.from_numpy(sums), torch.from_numpy(count), torch.from_numpy(nviews)]
-    reduce_partials(dist, t)
+    res = {}
+    for name, dst in (("all", None), ("root", 0)):
+        agg = _filled_aggregator(oracle, s, feats, mine)
+        agg.all_reduce(dst=dst)                                # the entry point's own combination step
+        assert agg.n_seen == 7
+        if rank == 0 or dst is None:
+            r = agg.result()
+            res[name] = dict(sums=agg.sum32.numpy().copy(), count=agg.count.numpy().copy(), nviews=agg.views.numpy().copy(),
+                             avg=r["avg_feats"].numpy(), coords=r["voxel_coords"].numpy(), xyz=r["xyz"].numpy(),
+                             hit_count=r["hit_count"].numpy())
+    if rank == 1:                                              # after an all-reduce every rank holds the scene
+        np.savez(out_path + ".rank1.npz", **{k: v for k, v in res["all"].items()})
     if rank == 0:
-        np.savez(out_path, sums=t[0].numpy(), count=t[1].numpy(), nviews=t[2].numpy())
+        np.savez(out_path, **{f"{n}_{k}": v for n, d in res.items() for k, v in d.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,13 +80,25 @@ def test_two_rank_view_sharding_equals_single_rank(tmp_path, oracle_mod):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
     got = np.load(out_path)
+    rank1 = np.load(out_path + ".rank1.npz")
     s, feats = _scene()
-    n_rows = s.n_vox + 1
-    count, sums, nviews = np.zeros(n_rows, np.int32), np.zeros((n_rows, 8), np.float32), np.zeros(n_rows, np.int32)
-    _project(oracle_mod, s, feats, range(7), count, sums, nviews)
-    assert np.array_equal(got["count"], count) and np.array_equal(got["nviews"], nviews)
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    single = _filled_aggregator(oracle_mod, s, feats, range(7))
+    r = single.result()
+    count, sums, nviews = single.count.numpy(), single.sum32.numpy(), single.views.numpy()
     assert count.sum() > 5000
-    np.testing.assert_allclose(got["sums"], sums, rtol=1e-5, atol=1e-6)
+    for name in ("all", "root"):
+        assert np.array_equal(got[f"{name}_count"], count) and np.array_equal(got[f"{name}_nviews"], nviews)
+        np.testing.assert_allclose(got[f"{name}_sums"], sums, rtol=1e-5, atol=1e-6)
+        # the files' rows: same voxels in the same order, same coordinates, fp16 means equal up to the fp32 summation order
+        assert np.array_equal(got[f"{name}_coords"], r["voxel_coords"].numpy())
+        assert np.array_equal(got[f"{name}_hit_count"], r["hit_count"].numpy())
+        assert got[f"{name}_xyz"].tobytes() == r["xyz"].numpy().tobytes()
+        np.testing.assert_allclose(got[f"{name}_avg"].astype(np.float32), r["avg_feats"].numpy().astype(np.float32), rtol=2e-3, atol=1e-4)
+    assert np.array_equal(rank1["count"], count) and np.array_equal(rank1["coords"], r["voxel_coords"].numpy())
+    assert rank1["sums"].tobytes() == got["all_sums"].tobytes()          # an all-reduce leaves the same bits on every rank
 
 
 def test_views_of_rank_partition():
