@@ -228,9 +228,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (getenv("VOXPROJ_DEBUG_EVALS")) heavy_t = -1;   // diagnostics only: the hit image then holds evaluation counts
     {
         ProfSpan sp; sp.begin(0, s1);
-        VP_HIP(hipMemsetAsync(status, 0, ST_CALL_WORDS * sizeof(int), s1));
-        VP_HIP(hipMemsetAsync(cnt_call, 0, size_t(n_rows) * sizeof(int), s1));
-        hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
+        // one launch clears the per-call status words and the per-call histogram
+        hipLaunchKernelGGL(k_zero_call, dim3((unsigned)((n_rows + 1023) / 1024)), dim3(256), 0, s1, status, cnt_call, (long long)n_rows);
         sp.end();
     }
     {
@@ -261,6 +260,10 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // the gather's work list: touched voxels by size class, largest first (needs the finished histogram)
         hipLaunchKernelGGL(k_worklist, dim3((unsigned)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD))), dim3(256), 0, s1, (const int *)cnt_call, heavy_t,
                            (long long)n_rows, work, status + ST_WORK0);
+        // the view table is phase 2's: computed behind the march, not in front of it (in pipelined mode a kernel with
+        // this many registers waits for a wavefront of the previous call's gather to retire; measured either way: no
+        // difference in the step time, so it sits where it cannot hold the march back)
+        hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
         sp.end();
     }
     if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));

@@ -146,6 +146,16 @@ __global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__
     if (lane == 0) near2[(long long)b * nblk + blk] = make_ulonglong2(lo, hi);
 }
 
+// per-call reset: the status words of this buffer set and the per-call hit histogram, in one launch
+__global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int *__restrict__ cnt_call, long long n_rows)
+{
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (blockIdx.x == 0 && threadIdx.x < ST_CALL_WORDS) status[threadIdx.x] = 0;
+    if (i + 3 < n_rows) *reinterpret_cast<int4 *>(cnt_call + i) = make_int4(0, 0, 0, 0);
+    else
+        for (long long j = i; j < n_rows; j++) cnt_call[j] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_viewtab: invert each view's 3x3 (double precision) for the phase-2 search boxes
 // ------------------------------------------------------------------------------------------------

@@ -250,6 +250,51 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     return ws
 
 
+class PreparedViewCalls:
+    """vp_project_features for a sequence of same-shaped calls on one scene, with everything that does not change between
+    calls bound once (shapes, intrinsics, ray options, outputs, workspace, stream): the per-call work on the host is two
+    pointer reads and one foreign call.  Used by the aggregator's one-view-per-call parity mode, where the kernels of a
+    call run for ~0.2 ms and the general wrapper's Python would otherwise set the pace.  The first call builds the
+    occupancy tables, the following ones reuse them (the caller keeps ``occ`` alive and unmodified meanwhile)."""
+
+    def __init__(self, occ, intr, opts5, count, out, grid_origin3, voxel_size, workspace, shape, views_hit=None):
+        import torch
+        self.B, self.V, self.H, self.W, self.C = (int(v) for v in shape)
+        _, self.dimz, self.dimy, self.dimx = (int(v) for v in occ.shape)
+        self.n_rows = int(count.shape[0])
+        self.dev = occ.device
+        self.keep = (occ, intr, count, out, views_hit)
+        self.ws = workspace
+        need = workspace_bytes(self.B, self.V, self.H, self.W, self.C, self.dimz, self.dimy, self.dimx, self.n_rows)
+        self.ptr = workspace.ensure(need, self.dev)
+        self.cap = workspace.capacity()
+        self.o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
+        self.g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
+        self.vs = ctypes.c_float(float(voxel_size))
+        self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.fn32, self.fn16 = lib().vp_project_features, lib().vp_project_features_f16
+        self.occ_ptr, self.intr_ptr = occ.data_ptr(), intr.data_ptr()
+        self.count_ptr, self.out_ptr = count.data_ptr(), out.data_ptr()
+        self.views_ptr = views_hit.data_ptr() if views_hit is not None else None
+        self.built = False
+        workspace.accel_key = None
+        workspace.last_shape = (self.B, self.V, self.H, self.W, self.C, self.dimz, self.dimy, self.dimx, self.n_rows)
+
+    def __call__(self, feats, vmi):
+        """feats: CUDA tensor [B,V,H,W,C] (float32 or float16, contiguous), vmi: CUDA float32 [B*V*16]; asynchronous."""
+        import torch
+        if torch.cuda.current_device() != self.dev.index:
+            torch.cuda.set_device(self.dev)       # the C-ABI works on the calling thread's current device
+        fn = self.fn16 if feats.dtype == torch.float16 else self.fn32
+        rc = fn(feats.data_ptr(), self.occ_ptr, vmi.data_ptr(), self.intr_ptr, self.o, self.count_ptr, self.out_ptr,
+                self.views_ptr, self.g, self.vs, self.B, self.V, self.H, self.W, self.C, self.dimz, self.dimy, self.dimx,
+                self.n_rows, self.ptr, self.cap, self.stream, VP_FLAG_REUSE_ACCEL if self.built else 0)
+        if rc != VP_OK:
+            self.built = False
+            check(rc)
+        self.built = True
+
+
 def hit_image(ws, device):
     """First-hit ID image of the last call on ``ws`` as an int32 [B,V,H,W] tensor (test hook)."""
     import torch
@@ -377,18 +422,30 @@ def build_occupancy_device(points_xyz, grid_origin3, voxel_size):
     return occ, lo
 
 
-def aggregate_view_f16(view_sum, view_count, run16, views, first_view, view_index, nonfinite):
+_agg_cache = {}
+
+
+def aggregate_view_f16(view_sum, view_count, run16, views, first_view, view_index, nonfinite, flag_index=0, stream=None):
     """vp_aggregate_view_f16 (aggregate_voxel_features_onthefly.py:307-313 over the rows hit in this view; leaves
-    view_sum / view_count zeroed).  Asynchronous on the current stream."""
+    view_sum / view_count zeroed).  ``nonfinite`` int32 tensor, element ``flag_index`` receives the view's NaN/Inf flag.
+    Asynchronous on ``stream`` (a raw hipStream_t value; default: torch's current stream).  The tensors' checks and
+    pointers are cached per argument set (the aggregator calls this once per view with the same tensors)."""
     import torch
-    n_rows, C = (int(v) for v in view_sum.shape)
-    assert view_sum.dtype == torch.float32 and view_sum.is_contiguous() and view_count.dtype == torch.int32
-    assert run16.dtype == torch.float16 and run16.is_contiguous() and tuple(run16.shape) == (n_rows, C)
-    assert views.dtype == torch.int32 and first_view.dtype == torch.int32 and nonfinite.dtype == torch.int32
-    stream = torch.cuda.current_stream(view_sum.device).cuda_stream
-    with torch.cuda.device(view_sum.device):
-        check(lib().vp_aggregate_view_f16(view_sum.data_ptr(), view_count.data_ptr(), run16.data_ptr(), views.data_ptr(),
-                                          first_view.data_ptr(), int(view_index), nonfinite.data_ptr(), n_rows, C, stream))
+    key = (view_sum.data_ptr(), view_count.data_ptr(), run16.data_ptr(), views.data_ptr(), first_view.data_ptr(), nonfinite.data_ptr())
+    c = _agg_cache.get("k")
+    if c is None or c[0] != key:
+        n_rows, C = (int(v) for v in view_sum.shape)
+        assert view_sum.dtype == torch.float32 and view_sum.is_contiguous() and view_count.dtype == torch.int32
+        assert run16.dtype == torch.float16 and run16.is_contiguous() and tuple(run16.shape) == (n_rows, C)
+        assert views.dtype == torch.int32 and first_view.dtype == torch.int32 and nonfinite.dtype == torch.int32
+        c = _agg_cache["k"] = (key, n_rows, C, lib().vp_aggregate_view_f16, view_sum.device)
+    _, n_rows, C, fn, dev = c
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    assert 0 <= flag_index < nonfinite.numel()
+    if torch.cuda.current_device() != dev.index:
+        torch.cuda.set_device(dev)
+    check(fn(key[0], key[1], key[2], key[3], key[4], int(view_index), key[5] + 4 * int(flag_index), n_rows, C, stream))
 
 
 def stream_read_gbs(buf, repeats=3):

@@ -105,7 +105,7 @@ def test_per_view_fp16_accumulate_matches_the_reference_dict_loop(oracle_mod):
         per_view.append(oracle_mod.dpf_select_outputs(occ, cnt, sums))
         view_sum.copy_(torch.from_numpy(sums))
         view_cnt.copy_(torch.from_numpy(cnt))
-        voxproj_host.aggregate_view_f16(view_sum, view_cnt, run16, views, first, v, flags[v:v + 1])
+        voxproj_host.aggregate_view_f16(view_sum, view_cnt, run16, views, first, v, flags, v)
         assert int(view_cnt.abs().sum()) == 0 and float(view_sum.abs().sum()) == 0.0      # scratch is clean again
     assert flags.cpu().tolist() == [0, 0, 0, 1, 0, 0]
     exp = oracle_mod.aggregate_views(per_view, [0.0, 0.0, 0.0], 0.1)

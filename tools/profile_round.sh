@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 evidence for profiles/: kernel trace + stats of the default bench command, FETCH_SIZE / WRITE_SIZE passes
+# (separate, as MI355X_MICROARCH.md prescribes), fp32 and fp16.  Run on the GPU box from the repo root:
+#   bash tools/profile_round.sh r02
+set -o pipefail
+tag=${1:-r02}
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+out=gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $out/trace_f16 -o t --output-format csv -- python3 bench.py --no-cpu-baseline --dtype f16 > $out/bench_f16_under_rocprof.log 2>&1 || exit 1
+for dt in f32 f16; do
+  rocprofv3 --pmc FETCH_SIZE -d $out/fetch_$dt -o c --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 128 --dtype $dt > $out/pmc_fetch_$dt.log 2>&1 || exit 1
+  rocprofv3 --pmc WRITE_SIZE -d $out/write_$dt -o c --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 128 --dtype $dt > $out/pmc_write_$dt.log 2>&1 || exit 1
+done
+rocprofv3 --kernel-trace --stats -d $out/trace_R4 -o t --output-format csv -- python3 bench.py --workload R4 --no-cpu-baseline > $out/bench_R4_under_rocprof.log 2>&1 || exit 1
+python3 tools/summarize_prof.py $out/trace $out/trace_f16 $out/fetch_f32 $out/write_f32 $out/fetch_f16 $out/write_f16 $out/trace_R4 > $out/summary.txt
+for f in $out/*.log; do echo "== $f"; grep '^{' $f | tail -1 | cut -c1-400; done >> $out/summary.txt
+python3 bench.py --write-pmc-json $out gpurun_out/${tag}_pmc_traffic.json >> $out/summary.txt
+# keep the merge small: the raw traces are large
+find $out -name "*kernel_trace.csv" -delete
