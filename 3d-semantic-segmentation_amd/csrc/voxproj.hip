@@ -505,7 +505,7 @@ int vp_upsample_features(const void *src_chw, int src_is_f16, int C, int h, int 
     const dim3 tgrid((unsigned)((P + 63) / 64), (unsigned)((C + 63) / 64));
     // cv::resize derives the scale from the destination size: inv_scale = dsize / ssize, scale = 1 / inv_scale
     const double scale_x = 1.0 / ((double)W / (double)w), scale_y = 1.0 / ((double)H / (double)h);
-    const unsigned ublocks = (unsigned)(((long long)H * W + 3) / 4);
+    const unsigned ublocks = (unsigned)(((long long)H * W + 4 * UPS_PIX - 1) / (4 * UPS_PIX));
 #define VP_UPS(TS_, TD_, VEC_) hipLaunchKernelGGL((k_upsample_hwc<TS_, TD_, VEC_>), dim3(ublocks), dim3(256), 0, stream, \
         (const TS_ *)workspace, (TD_ *)dst_hwc, C, h, w, H, W, scale_x, scale_y)
     const bool al16 = (((uintptr_t)workspace | (uintptr_t)dst_hwc) & 15) == 0;

@@ -55,50 +55,58 @@ struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
 template <typename T>
 struct VecOf<T, 1> { typedef T type; };
 
+constexpr int UPS_PIX = 8;   // consecutive output pixels per wavefront (fewer, longer-lived waves: the launch rate of
+                             // one-pixel waves, not memory, bounded the first version of this kernel)
+
 template <typename TS, typename TD, int VEC>
 __global__ __launch_bounds__(256) void k_upsample_hwc(const TS *__restrict__ src, TD *__restrict__ dst, int C, int h, int w,
                                                       int H, int W, double scale_x, double scale_y)
 {
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= (long long)H * W) return;
+    const long long HW = (long long)H * W;
+    const long long pix0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * UPS_PIX;
     const int lane = threadIdx.x & 63;
-    const int dy = (int)(pix / W), dx = (int)(pix - (long long)dy * W);
-    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= (float)sx;
-    if (sx < 0) { sx = 0; fx = 0.f; }
-    if (sx >= w - 1) { sx = w - 1; fx = 0.f; }
-    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
-    const int sy = (int)floorf(fy);
-    fy -= (float)sy;
-    const int sy0 = min(max(sy, 0), h - 1), sy1 = min(max(sy + 1, 0), h - 1);
-    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-    const bool two = sx < w - 1;      // at the right border OpenCV copies S[sx] (x >= xmax: D[dx] = S[sx] * 1)
-    const TS *s00 = src + ((long long)sy0 * w + sx) * C, *s10 = src + ((long long)sy1 * w + sx) * C;
-    TD *o = dst + pix * C;
     typedef typename VecOf<TS, VEC>::type VS;
     typedef typename VecOf<TD, VEC>::type VD;
-    for (int c = lane * VEC; c < C; c += 64 * VEC) {
-        const VS p00 = *reinterpret_cast<const VS *>(s00 + c), p10 = *reinterpret_cast<const VS *>(s10 + c);
-        VS p01 = p00, p11 = p10;
-        if (two) {
-            p01 = *reinterpret_cast<const VS *>(s00 + C + c);
-            p11 = *reinterpret_cast<const VS *>(s10 + C + c);
-        }
-        VD res;
+#pragma unroll 2
+    for (int q = 0; q < UPS_PIX; q++) {
+        const long long pix = pix0 + q;
+        if (pix >= HW) return;
+        const int dy = (int)(pix / W), dx = (int)(pix - (long long)dy * W);
+        float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { sx = 0; fx = 0.f; }
+        if (sx >= w - 1) { sx = w - 1; fx = 0.f; }
+        float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const int sy0 = min(max(sy, 0), h - 1), sy1 = min(max(sy + 1, 0), h - 1);
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        const bool two = sx < w - 1;      // at the right border OpenCV copies S[sx] (x >= xmax: D[dx] = S[sx] * 1)
+        const TS *s00 = src + ((long long)sy0 * w + sx) * C, *s10 = src + ((long long)sy1 * w + sx) * C;
+        TD *o = dst + pix * C;
+        for (int c = lane * VEC; c < C; c += 64 * VEC) {
+            const VS p00 = *reinterpret_cast<const VS *>(s00 + c), p10 = *reinterpret_cast<const VS *>(s10 + c);
+            VS p01 = p00, p11 = p10;
+            if (two) {
+                p01 = *reinterpret_cast<const VS *>(s00 + C + c);
+                p11 = *reinterpret_cast<const VS *>(s10 + C + c);
+            }
+            VD res;
 #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            float q00, q01, q10, q11;
-            if constexpr (VEC == 1) { q00 = (float)p00; q01 = (float)p01; q10 = (float)p10; q11 = (float)p11; }
-            else { q00 = (float)p00[e]; q01 = (float)p01[e]; q10 = (float)p10[e]; q11 = (float)p11[e]; }
-            const float r0 = two ? q00 * a0 + q01 * a1 : q00 * 1.f;
-            const float r1 = two ? q10 * a0 + q11 * a1 : q10 * 1.f;
-            const float v = r0 * b0 + r1 * b1;
-            const TS back = (TS)v;                   // PTD:126 arr_upsampled.astype(arr.dtype)
-            if constexpr (VEC == 1) res = (TD)back;  // PTD:152 .float() (exact) or kept in the file's dtype
-            else res[e] = (TD)back;
+            for (int e = 0; e < VEC; e++) {
+                float q00, q01, q10, q11;
+                if constexpr (VEC == 1) { q00 = (float)p00; q01 = (float)p01; q10 = (float)p10; q11 = (float)p11; }
+                else { q00 = (float)p00[e]; q01 = (float)p01[e]; q10 = (float)p10[e]; q11 = (float)p11[e]; }
+                const float r0 = two ? q00 * a0 + q01 * a1 : q00 * 1.f;
+                const float r1 = two ? q10 * a0 + q11 * a1 : q10 * 1.f;
+                const float v = r0 * b0 + r1 * b1;
+                const TS back = (TS)v;                   // PTD:126 arr_upsampled.astype(arr.dtype)
+                if constexpr (VEC == 1) res = (TD)back;  // PTD:152 .float() (exact) or kept in the file's dtype
+                else res[e] = (TD)back;
+            }
+            __builtin_nontemporal_store(res, reinterpret_cast<VD *>(o + c));   // written once, read by another kernel later
         }
-        *reinterpret_cast<VD *>(o + c) = res;
     }
 }
 

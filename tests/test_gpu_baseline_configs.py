@@ -110,3 +110,57 @@ def test_config5_rgb_500k_voxels_eight_views_vs_oracle(oracle_mod):
     assert np.array_equal(agg.first_view.cpu().numpy().astype(np.int64), ref_first)
     assert np.array_equal(torch.cat([uv_t, uv_t2]).cpu().numpy(), ref_uv)
     assert ref_hits.sum() > N                                 # the scene is seen: > 1 view per voxel on average
+
+
+def test_config3_full_300_view_pipelined_pass_counts_vs_oracle(oracle_mod):
+    # The WHOLE metric workload the way bench.py drives it -- 300 views, 32 per pipelined call, production heavy-voxel
+    # threshold, a pool of 32 resident maps cycled -- against the oracle's ray-march of all 300 views: per-voxel pixel
+    # counts and per-voxel view counts bit-exact.  The feature sums (326 GB of rows) cannot be replayed on the host; they
+    # are checked through a checksum of checksums: per channel, the sum over all voxel rows must equal the sum of the
+    # rows of all hit pixels, evaluated independently in float64 from the ORACLE's first-hit images.
+    import voxproj_host
+    dev = torch.device(DEV)
+    n_vox, n_views, W, H, C, chunk = 200000, 300, 968, 548, 512, 32
+    s = make_scene(n_vox, n_views, W, H, seed=0)
+    n_rows = n_vox + 1
+    occ64 = s.occ[None].astype(np.int64)
+    pool = torch.empty((1, chunk, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(chunk, H, W, C, dev, seed=0, out=pool[0])
+    occ_t = torch.from_numpy(occ64).to(dev)
+    c2w_t = torch.from_numpy(s.c2w).to(dev)
+    intr_t = torch.from_numpy(s.intr[None]).to(dev)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    ws = voxproj_host.Workspace()
+    opts, origin = [float(v) for v in s.opts()], [float(v) for v in s.grid_origin]
+    vmis = []
+    for a in range(0, n_views, chunk):
+        b = min(n_views, a + chunk)
+        vmis.append(c2w_t[a:b].reshape(-1).contiguous())
+        voxproj_host.project_features_raw(pool[:, :b - a], occ_t, vmis[-1], intr_t, opts, count_t, out_t, origin, s.voxel_size,
+                                          workspace=ws, sync=False, reuse_accel=(a > 0 or None), pipeline=True, views_hit=views_t)
+    voxproj_host.workspace_status(ws, dev)
+    ctr = voxproj_host.counters(ws, dev)
+    assert ctr["bad_id"] == 0 and ctr["box_miss"] == 0
+    count_ref = np.zeros(n_rows, np.int64)
+    views_ref = np.zeros(n_rows, np.int64)
+    tot = torch.zeros(C, dtype=torch.float64, device=dev)
+    tot_abs = torch.zeros(C, dtype=torch.float64, device=dev)
+    for a in range(0, n_views, chunk):
+        b = min(n_views, a + chunk)
+        hits = oracle_mod.first_hit(occ64, s.c2w[a:b].reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, 1, b - a)
+        count_ref += np.bincount(hits.reshape(-1), minlength=n_rows)
+        for v in range(b - a):
+            ids = np.unique(hits[0, v])
+            views_ref[ids[ids > 0]] += 1
+        mask = torch.from_numpy(hits[0] > 0).to(dev)                      # [v,H,W]: view a+v reads pool slot v
+        for v in range(b - a):
+            rows = pool[0, v][mask[v]].double()
+            tot += rows.sum(0)
+            tot_abs += rows.abs().sum(0)
+    count_ref[0] = 0
+    assert np.array_equal(count_t.cpu().numpy().astype(np.int64), count_ref)
+    assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
+    assert int(count_ref.sum()) > 0.99 * n_views * H * W
+    assert ((out_t.double().sum(0) - tot).abs() <= 1e-6 * tot_abs).all()
