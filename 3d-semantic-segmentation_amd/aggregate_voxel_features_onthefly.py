@@ -294,7 +294,7 @@ def main(argv=None):
         intr, c2w = ptd.camera_for(entry, cams, args.downsample_factor)                            # PTD:132-172
         if agg is None:
             agg = VoxelFeatureAggregator(occ, grid_origin, voxel_size, feats.shape[-1], args.mode, dev)
-        same = batch_intr is not None and torch.equal(batch_intr, intr) and batch_f[0].shape == feats.shape
+        same = bool(batch_f) and torch.equal(batch_intr, intr) and batch_f[0].shape == feats.shape
         if batch_f and (not same or len(batch_f) >= (1 if args.mode == "parity" else args.views_per_call)):
             agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
             batch_f, batch_c = [], []

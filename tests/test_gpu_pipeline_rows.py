@@ -417,3 +417,31 @@ def test_c_abi_from_a_plain_hip_program(tmp_path, oracle_mod):
     for i in ids:
         assert got[i][0] == count[i]
         assert np.array_equal(np.array(got[i][1], np.float32), out[i]), i      # %.9g round-trips float32
+
+
+def test_entry_point_writes_checkpoints_and_the_feature_ply(tmp_path):
+    # AGG:318-352 (a consolidated checkpoint every 20 views) and AGG:425-440 (the final ASCII .ply with the first three
+    # channels as uchar rgb), in both modes; the parity mode's checkpoint equals a 20-view run's final result
+    import aggregate_voxel_features_onthefly as agg
+    s, ply, lseg, cam_json = _write_scene_files(tmp_path, n_views=22, C=8)
+    common = ["--lseg_dir", str(lseg), "--cam_params", str(cam_json), "--voxel_ply", str(ply), "--views_per_call", "3"]
+    for mode in ("parity", "fast"):
+        out_dir = tmp_path / mode
+        agg.main(["--mode", mode, "--checkpoint_dir", str(out_dir)] + common)
+        ck = torch.load(out_dir / "checkpoint_features_20.pt")
+        assert set(ck) == {"xyz", "avg_feats", "hit_count", "voxel_coords"}
+        assert ck["xyz"].dtype == torch.float64 and ck["avg_feats"].dtype == torch.float16 and ck["hit_count"].dtype == torch.int32
+        fin = torch.load(out_dir / f"ALL_nonzero_voxel_features_22_vox{s.n_vox}.pt")
+        assert fin["xyz"].shape[0] >= ck["xyz"].shape[0] > 300
+        lines = (out_dir / f"ALL_nonzero_voxels_with_features_22_vox{s.n_vox}.ply").read_text().splitlines()
+        n = fin["xyz"].shape[0]
+        assert lines[:3] == ["ply", "format ascii 1.0", f"element vertex {n}"] and lines[9] == "end_header" and len(lines) == 10 + n
+        x, y, z, r, g, b = lines[10].split()
+        assert np.allclose([float(x), float(y), float(z)], fin["xyz"][0].numpy(), rtol=1e-6)
+        exp_rgb = (np.clip(fin["avg_feats"][0, :3].numpy(), 0, 1) * 255).astype(np.uint8)
+        assert [int(r), int(g), int(b)] == exp_rgb.tolist()
+    out20 = tmp_path / "parity20"
+    agg.main(["--mode", "parity", "--checkpoint_dir", str(out20), "--max_images", "20"] + common)
+    ck = torch.load(tmp_path / "parity" / "checkpoint_features_20.pt")
+    fin20 = torch.load(out20 / f"ALL_nonzero_voxel_features_20_vox{s.n_vox}.pt")
+    assert torch.equal(ck["voxel_coords"], fin20["voxel_coords"]) and torch.equal(ck["avg_feats"], fin20["avg_feats"])

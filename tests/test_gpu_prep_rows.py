@@ -132,3 +132,37 @@ def test_parity_aggregator_reports_nonfinite_views(capsys):
     agg.result()
     out = capsys.readouterr().out
     assert "NaN or Inf detected in projected features for view 1" in out and "view 0" not in out and "view 2" not in out
+
+
+def test_new_entry_points_refuse_bad_arguments():
+    # loud failures instead of undefined behaviour: duplicate voxel IDs on the colour path, points that cannot be binned,
+    # a float16 destination for a float32 source, a workspace that is too small
+    import ctypes
+
+    import voxproj_host
+    dev = torch.device(DEV)
+    occ = torch.zeros(3, 4, 5, dtype=torch.int32, device=dev)
+    occ[0, 0, 0] = 1
+    occ[1, 2, 3] = 1                                                   # the same ID in two cells
+    c2w = torch.eye(4, device=dev)[None].contiguous()
+    intr = torch.tensor([[10.0, 10.0, 4.0, 4.0]], device=dev)
+    img = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=dev)
+    with pytest.raises(voxproj_host.VoxprojError, match="more than one cell"):
+        voxproj_host.project_colors_raw(occ, c2w, intr, [0, 0, 0], 0.1, img, torch.zeros(2, 3, device=dev),
+                                        torch.zeros(2, dtype=torch.int32, device=dev))
+    occ[1, 2, 3] = 7
+    with pytest.raises(voxproj_host.VoxprojError, match="outside"):
+        voxproj_host.project_colors_raw(occ, c2w, intr, [0, 0, 0], 0.1, img, torch.zeros(2, 3, device=dev),
+                                        torch.zeros(2, dtype=torch.int32, device=dev))
+    pts = torch.tensor([[0.0, 0.0, 0.0], [float("nan"), 1.0, 2.0]], device=dev)
+    with pytest.raises(voxproj_host.VoxprojError, match="not finite"):
+        voxproj_host.build_occupancy_device(pts, [0, 0, 0], 0.1)
+    L = voxproj_host.lib()
+    src = torch.zeros(4, 3, 3, device=dev)
+    dst = torch.zeros(6, 6, 4, dtype=torch.float16, device=dev)
+    ws = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    p = ctypes.c_void_p
+    assert L.vp_upsample_features(p(src.data_ptr()), 0, 4, 3, 3, p(dst.data_ptr()), 1, 6, 6, p(ws.data_ptr()), 4096, None) == -1
+    assert b"float16 destination" in L.vp_last_error()
+    assert L.vp_upsample_features(p(src.data_ptr()), 0, 4, 3, 3, p(dst.data_ptr()), 0, 6, 6, p(ws.data_ptr()), 16, None) == -2
+    assert b"workspace" in L.vp_last_error()
