@@ -24,7 +24,7 @@
 //   vp_common.h  error text, timing spans, VP_FLAG_PIPELINE stream state, Params, workspace Layout
 //   vp_tables.h  arithmetic contract helpers, occupancy-derived tables, view table
 //   vp_march.h   phase 1 (k_first_hit)
-//   vp_gather.h  phase 2 (k_gather, k_gather_heavy)
+//   vp_gather.h  work list and phase 2 (k_worklist, k_gather: one wavefront per voxel, one workgroup per heavy voxel)
 //   vp_aux.h     RGB projection, nearest-voxel map, streaming-read probe
 //   vp_prep.h    feature-map up-sampler (PTD:119-127), occupancy builder (BSO:30-53)
 //   vp_aggregate.h  the aggregator's per-view fp16 accumulate over the hit rows (AGG:307-313)
@@ -63,8 +63,6 @@
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
-
-constexpr int HEAVY_BLOCKS = 128;
 
 // rows in flight per wavefront in the fp16 gather
 #ifndef VP_F16_U
@@ -122,7 +120,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     hipStream_t s0 = (hipStream_t)stream_;
 
     // buffer set and streams: plain calls use set 0 on the caller's stream only; pipelined calls alternate sets
-    // and run phase 1 + the heavy-voxel kernel on the side stream
+    // and run phase 1 on the side stream
     const bool pipe = (flags & VP_FLAG_PIPELINE) != 0;
     PipeState *ps = pipe_state(workspace, pipe);
     if (pipe && !ps) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
@@ -134,7 +132,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     } else if (ps && (ps->used[0] || ps->used[1])) {
         // a plain call after pipelined ones on this workspace: drain the side streams first
         VP_HIP(hipStreamSynchronize(ps->side));
-        VP_HIP(hipStreamSynchronize(ps->side2));
         ps->used[0] = ps->used[1] = false;
     }
     int *status = (int *)(ws + l.status[q]);
@@ -193,8 +190,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
         if (pipe) {
             VP_HIP(hipStreamSynchronize(ps->side));
-            VP_HIP(hipStreamSynchronize(ps->side2));
-            VP_HIP(hipStreamSynchronize(s0));
+                VP_HIP(hipStreamSynchronize(s0));
         }
         ProfSpan sp; sp.begin(0, s0);
         VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), s0));
@@ -217,7 +213,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     }
 
     if (pipe) {
-        VP_HIP(hipEventRecord(ps->entry, s0));
         // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
         if (ps->used[q]) VP_HIP(hipStreamWaitEvent(s1, ps->call_done[q], 0));
     }
@@ -276,29 +271,14 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
-    // heavy voxels: beside the normal gather on a third stream when pipelined (they write output rows, so they follow
-    // everything the caller queued before this call and the previous call's gather), else in front of it
-    hipStream_t sh = pipe ? ps->side2 : s0;
-    if (pipe) {
-        VP_HIP(hipStreamWaitEvent(sh, ps->entry, 0));
-        VP_HIP(hipStreamWaitEvent(sh, ps->fh_done[q], 0));
-    }
+    // heavy voxels are the first workgroups of the same launch (vp_gather.h)
+    if (pipe) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
     {
-        ProfSpan sp; sp.begin(3, sh);
-        VP_DISPATCH_KVU(k_gather_heavy, vec_ok, C, dim3(HEAVY_BLOCKS), dim3(GW * 64), 0, sh, g, p);
-        sp.end();
-    }
-    if (pipe) {
-        VP_HIP(hipEventRecord(ps->heavy_done[q], sh));
-        VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
-    }
-    if (blocks_n > 0) {
         ProfSpan sp; sp.begin(2, s0);
-        VP_DISPATCH_KVU(k_gather, vec_ok, C, dim3(blocks_n), dim3(256), 0, s0, g, p);
+        VP_DISPATCH_KVU(k_gather, vec_ok, C, dim3(HEAVY_BLOCKS + (blocks_n > 0 ? blocks_n : 0)), dim3(256), 0, s0, g, p);
         sp.end();
     }
     if (pipe) {
-        VP_HIP(hipStreamWaitEvent(s0, ps->heavy_done[q], 0));
         VP_HIP(hipEventRecord(ps->call_done[q], s0));
         ps->used[q] = true;
         ps->last_q = q;
@@ -336,7 +316,6 @@ static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WO
 {
     if (PipeState *ps = pipe_state(workspace, false)) {
         VP_HIP(hipStreamSynchronize(ps->side));
-        VP_HIP(hipStreamSynchronize(ps->side2));
     }
     VP_HIP(hipMemcpyAsync(st, workspace, 2 * align256(ST_WORDS * sizeof(int)), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
@@ -435,7 +414,6 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
     PipeState *ps = pipe_state(const_cast<void *>(workspace), false);
     if (ps) {
         VP_HIP(hipStreamSynchronize(ps->side));
-        VP_HIP(hipStreamSynchronize(ps->side2));
     }
     VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + off, size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
@@ -588,15 +566,11 @@ int vp_workspace_release(void *workspace)
         if (g_pipes[i].first == workspace) {
             PipeState *ps = g_pipes[i].second;
             (void)hipStreamSynchronize(ps->side);
-            (void)hipStreamSynchronize(ps->side2);
             (void)hipStreamDestroy(ps->side);
-            (void)hipStreamDestroy(ps->side2);
             for (int q = 0; q < 2; q++) {
                 (void)hipEventDestroy(ps->fh_done[q]);
-                (void)hipEventDestroy(ps->heavy_done[q]);
                 (void)hipEventDestroy(ps->call_done[q]);
             }
-            (void)hipEventDestroy(ps->entry);
             delete ps;
             g_pipes.erase(g_pipes.begin() + i);
             break;

@@ -31,7 +31,7 @@ struct Profile {
     std::mutex mu;
     bool on = false;
     std::vector<hipEvent_t> pool;    // event pairs
-    std::vector<int> kind;           // per pair: 0 prep, 1 first_hit, 2 gather, 3 heavy
+    std::vector<int> kind;           // per pair: 0 prep, 1 first_hit (+ work list, view table), 2 gather (incl. heavy voxels)
     size_t used = 0;                 // pairs in use
     // returns the pair index, or -1
     int next(int k)
@@ -75,12 +75,8 @@ struct PipeState;
 std::vector<std::pair<void *, PipeState *>> g_pipes;
 struct PipeState {
     hipStream_t side = nullptr;    // phase 1
-    hipStream_t side2 = nullptr;   // heavy-voxel kernel (its big workgroups are slow to place next to the gather;
-                                   // on a stream of its own it cannot hold up the next call's phase 1)
     hipEvent_t fh_done[2] = {nullptr, nullptr};      // phase 1 of buffer set q finished (side stream)
-    hipEvent_t heavy_done[2] = {nullptr, nullptr};   // heavy-voxel kernel of set q finished (side stream)
     hipEvent_t call_done[2] = {nullptr, nullptr};    // everything of the call that used set q finished (caller's stream)
-    hipEvent_t entry = nullptr;                      // caller's stream position at call entry
     bool used[2] = {false, false};
     long long calls = 0;
     int last_q = 0;
@@ -136,13 +132,10 @@ PipeState *pipe_state(void *workspace, bool create)
     if (!create) return nullptr;
     PipeState *ps = new PipeState();
     // (a high-priority side stream was measured: no effect on the pipelined step time, so plain streams)
-    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ps->side2, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess;
     for (int q = 0; q < 2 && ok; q++)
         ok = hipEventCreateWithFlags(&ps->fh_done[q], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&ps->heavy_done[q], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ps->call_done[q], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&ps->entry, hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete ps; return nullptr; }
     g_pipes.emplace_back(workspace, ps);
     return ps;

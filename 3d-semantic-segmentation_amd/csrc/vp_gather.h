@@ -1,5 +1,6 @@
 // vp_gather.h -- phase 2: one wavefront per voxel gathers and sums the feature rows of the pixels that first-hit it
-// (k_gather), a whole workgroup for voxels with very many pixels (k_gather_heavy).  Included by voxproj.hip only.
+// (k_gather); the voxels with very many pixels are shared by the four wavefronts of the launch's first workgroups.
+// Included by voxproj.hip only.
 #pragma once
 
 namespace {
@@ -226,7 +227,8 @@ struct GatherArgs {
     int *status;
 };
 
-constexpr int GW = 16;   // wavefronts per k_gather_heavy workgroup
+constexpr int GW = 4;            // wavefronts that share one heavy voxel (= one k_gather workgroup)
+constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather that take the heavy voxels
 
 // views whose first ID tile is fetched together by the one-wavefront gather (1 = one view at a time)
 #ifndef VP_GATHER_G16
@@ -403,7 +405,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
     }
 }
 
-// Heavy role: the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
+// Heavy role (the first HEAVY_BLOCKS workgroups of k_gather): the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
 // in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
 // each wavefront sums its range in raster order, and the partial rows are combined through LDS in
 // wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
@@ -546,8 +548,26 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
     // march waves of the next call that share the SIMD in pipelined mode.
     __builtin_amdgcn_s_setprio(3);
+    __shared__ __attribute__((aligned(16))) float part[GW][64 * K * VEC];
+    __shared__ int part_found[GW];
+    if (blockIdx.x < HEAVY_BLOCKS) {
+        // Heavy role: the first workgroups of the grid -- so they start before anything else, the longest jobs first --
+        // take the voxels that collected more than heavy_t pixels in this call, one voxel per workgroup at a time, the
+        // four wavefronts splitting each view's box rows (gather_voxel_block).  First the search boxes; on a pixel-count
+        // mismatch nothing was stored: redo over whole images.
+        const int n_heavy = *g.n_heavy;
+        for (int h = blockIdx.x; h < n_heavy; h += HEAVY_BLOCKS) {
+            const int id = g.heavy_list[h];
+            const int expected = g.cnt_call[id];
+            if (!gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, false)) {
+                if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+                gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
+            }
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long w = (long long)(blockIdx.x - HEAVY_BLOCKS) * 4 + (threadIdx.x >> 6);
     int id = 0;
 #pragma unroll
     for (int k = WORK_CLASSES - 1; k >= 0; k--) {
@@ -558,23 +578,6 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     if (id == 0) return;
     const int expected = g.cnt_call[id];
     gather_voxel_wave<K, VEC, U, VP_GATHER_G(VEC)>(g, p, id, expected, lane);
-}
-
-template <int K, int VEC, int U>
-__global__ __launch_bounds__(GW * 64) void k_gather_heavy(GatherArgs g, Params p)
-{
-    __shared__ __attribute__((aligned(16))) float part[GW][64 * K * VEC];
-    __shared__ int part_found[GW];
-    const int n_heavy = *g.n_heavy;
-    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const int id = g.heavy_list[h];
-        const int expected = g.cnt_call[id];
-        // first try the search boxes; on a pixel-count mismatch nothing was stored: redo over whole images
-        if (!gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, false)) {
-            if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-            gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
-        }
-    }
 }
 
 }  // namespace

@@ -564,13 +564,11 @@ def main():
         ph, nt = int(count.sum().item()), int((count > 0).sum().item())
         hit_px += ph
         touched += nt
-        # k_gather proper: voxels above the library's per-call threshold (256 + 64*B*V pixels) are summed by
-        # k_gather_heavy, so their rows and output RMW do not count for this kernel
+        # voxels above the library's per-call threshold (256 + 64*B*V pixels) are summed by the leading workgroups of
+        # the same k_gather launch: every hit pixel's row and every touched output row count for this kernel
         heavy = count > (int(os.environ.get("VOXPROJ_HEAVY_T", "0")) or (256 + 64 * len(calls[ci][1])))
-        ph_heavy, nt_heavy = int(count[heavy].sum().item()), int(heavy.sum().item())
-        heavy_px += ph_heavy
-        gather_bytes += ((ph - ph_heavy) * C * esize + (nt - nt_heavy) * C * 4 * 2 + len(calls[ci][1]) * H * W * 4
-                         + n_rows * 4 * 2)
+        heavy_px += int(count[heavy].sum().item())
+        gather_bytes += ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
         c1 = voxproj_host.counters(ws, dev)
         for k in c1:
             cnt[k] = cnt.get(k, 0) + c1[k]

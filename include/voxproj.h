@@ -48,7 +48,7 @@ enum {
     VP_FLAG_PIPELINE = 8,    /* asynchronous job mode (excludes VP_FLAG_SYNC): phase 1 (ray-march) runs on a
                                 library-owned side stream -- held to a few wavefronts per CU -- so that the
                                 march of this call overlaps the gather of the previous call on the same
-                                workspace (two buffer sets alternate; heavy voxels on a third stream).  The
+                                workspace (two buffer sets alternate).  The
                                 gather and every write to count/out/views_hit stay on `stream`, in order.
                                 The caller promises that occ, vmi and intr are not being written by work
                                 still pending on `stream`, keeps them alive and unchanged until the stream
@@ -170,7 +170,8 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
  * vp_profile_enable(1) starts recording for subsequent vp_project_features calls of this process;
  * vp_profile_read synchronises the recorded events and returns, per kernel group, the summed
  * milliseconds and the number of launches: [0] = table preparation (memsets, occupancy tables, view
- * table), [1] = k_first_hit (phase 1), [2] = k_gather (phase 2), [3] = k_gather_heavy; then clears
+ * table), [1] = k_first_hit + work list + view table (phase 1), [2] = k_gather (phase 2, heavy voxels included), [3] = unused
+ * since ABI v2 (always 0: heavy voxels are part of the k_gather launch); then clears
  * the record.
  */
 int vp_profile_enable(int on);
