@@ -128,7 +128,8 @@ class VoxelFeatureAggregator:
                 self.flush()
                 self._prep_intr = intr
                 self._prep = voxproj_host.PreparedViewCalls(self.occ, intr, self._opts(W, H), self._cnt, self._sum,
-                                                            self.grid_origin, self.voxel_size, self.ws, (1, 1, H, W, C))
+                                                            self.grid_origin, self.voxel_size, self.ws, (1, 1, H, W, C),
+                                                            flags=voxproj_host.VP_FLAG_SERIAL_SUMS)   # the reference's bits
                 self._prep_key = key
             for v in range(V):
                 self._prep(feats[v], vmis[v])

@@ -220,6 +220,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // ---- phase 1 (on s1) ----
     int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
     if (const char *e = getenv("VOXPROJ_HEAVY_T")) heavy_t = atoi(e) > 0 ? atoi(e) : heavy_t;
+    if (flags & VP_FLAG_SERIAL_SUMS) heavy_t = 2147483647;
     if (getenv("VOXPROJ_DEBUG_EVALS")) heavy_t = -1;   // diagnostics only: the hit image then holds evaluation counts
     {
         ProfSpan sp; sp.begin(0, s1);

@@ -18,6 +18,7 @@ VP_FLAG_REUSE_ACCEL = 2
 VP_FLAG_EXACT_MARCH = 4
 VP_FLAG_PIPELINE = 8
 VP_FLAG_VERIFY_ACCEL = 16
+VP_FLAG_SERIAL_SUMS = 32
 
 _lib = None
 _lock = threading.Lock()
@@ -257,7 +258,7 @@ class PreparedViewCalls:
     call run for ~0.2 ms and the general wrapper's Python would otherwise set the pace.  The first call builds the
     occupancy tables, the following ones reuse them (the caller keeps ``occ`` alive and unmodified meanwhile)."""
 
-    def __init__(self, occ, intr, opts5, count, out, grid_origin3, voxel_size, workspace, shape, views_hit=None):
+    def __init__(self, occ, intr, opts5, count, out, grid_origin3, voxel_size, workspace, shape, views_hit=None, flags=0):
         import torch
         self.B, self.V, self.H, self.W, self.C = (int(v) for v in shape)
         _, self.dimz, self.dimy, self.dimx = (int(v) for v in occ.shape)
@@ -276,6 +277,7 @@ class PreparedViewCalls:
         self.occ_ptr, self.intr_ptr = occ.data_ptr(), intr.data_ptr()
         self.count_ptr, self.out_ptr = count.data_ptr(), out.data_ptr()
         self.views_ptr = views_hit.data_ptr() if views_hit is not None else None
+        self.flags = int(flags)
         self.built = False
         workspace.accel_key = None
         workspace.last_shape = (self.B, self.V, self.H, self.W, self.C, self.dimz, self.dimy, self.dimx, self.n_rows)
@@ -288,7 +290,7 @@ class PreparedViewCalls:
         fn = self.fn16 if feats.dtype == torch.float16 else self.fn32
         rc = fn(feats.data_ptr(), self.occ_ptr, vmi.data_ptr(), self.intr_ptr, self.o, self.count_ptr, self.out_ptr,
                 self.views_ptr, self.g, self.vs, self.B, self.V, self.H, self.W, self.C, self.dimz, self.dimy, self.dimx,
-                self.n_rows, self.ptr, self.cap, self.stream, VP_FLAG_REUSE_ACCEL if self.built else 0)
+                self.n_rows, self.ptr, self.cap, self.stream, self.flags | (VP_FLAG_REUSE_ACCEL if self.built else 0))
         if rc != VP_OK:
             self.built = False
             check(rc)

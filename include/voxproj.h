@@ -54,6 +54,11 @@ enum {
                                 still pending on `stream`, keeps them alive and unchanged until the stream
                                 has been synchronised (vp_workspace_status does), and uses one stream per
                                 workspace.                                                            */
+    VP_FLAG_SERIAL_SUMS = 32,  /* sum EVERY voxel with one wavefront in (b, v, y, x) order, however many pixels it got in
+                                the call: no voxel takes the four-wavefront heavy path, so all sums are bit-identical to the
+                                serial order of oracle/projector_oracle.c (the heavy path is within 1e-4, not bit-equal).
+                                For callers that round the sums afterwards and promise the reference's bits -- the
+                                aggregator's parity mode (DPF:252 rounds to float16).  Slower only when a voxel is large. */
     VP_FLAG_VERIFY_ACCEL = 16  /* blocking calls only (ignored with VP_FLAG_PIPELINE or VP_FLAG_REUSE_ACCEL): the
                                 workspace has not been written by anyone else since the previous call on it;
                                 compare the occupancy grid with the 32-bit copy kept from the call that built

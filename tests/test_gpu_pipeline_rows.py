@@ -445,3 +445,35 @@ def test_entry_point_writes_checkpoints_and_the_feature_ply(tmp_path):
     ck = torch.load(tmp_path / "parity" / "checkpoint_features_20.pt")
     fin20 = torch.load(out20 / f"ALL_nonzero_voxel_features_20_vox{s.n_vox}.pt")
     assert torch.equal(ck["voxel_coords"], fin20["voxel_coords"]) and torch.equal(ck["avg_feats"], fin20["avg_feats"])
+
+
+def test_parity_aggregator_is_bit_exact_with_large_voxels_under_production_settings(oracle_mod, monkeypatch):
+    # Cameras a few voxels from a wall: single voxels collect far more than the production heavy threshold (256 + 64
+    # pixels for a one-view call).  The parity mode promises the reference's bits (per-view sums rounded to float16,
+    # DPF:252), so it asks the projector for serial sums (VP_FLAG_SERIAL_SUMS) -- no VOXPROJ_HEAVY_T override here.
+    from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
+    from synthetic_scene import make_features_np, make_scene
+    monkeypatch.delenv("VOXPROJ_HEAVY_T", raising=False)
+    s = make_scene(2000, 4, 96, 64, seed=33, room=(5.0, 4.0, 2.4))
+    c2w = s.c2w.copy()
+    for v in range(4):                                            # move every camera to 3 voxels from the wall it faces
+        wall = s.points[np.argmax(s.points @ c2w[v, :3, 2])]
+        c2w[v, :3, 3] = wall - c2w[v, :3, 2] * np.float32(3.0 * s.voxel_size)
+    C = 16
+    feats = make_features_np(4, 64, 96, C, seed=33)
+    n_rows = s.n_vox + 1
+    per_view, biggest = [], 0
+    for v in range(4):
+        cnt = np.zeros(n_rows, np.int32)
+        sums = np.zeros((n_rows, C), np.float32)
+        oracle_mod.project_features(feats[None, v:v + 1], s.occ[None].astype(np.int64), c2w[v].reshape(-1), s.intr[None], s.opts(),
+                                    s.grid_origin, s.voxel_size, cnt, sums)
+        biggest = max(biggest, int(cnt.max()))
+        per_view.append(oracle_mod.dpf_select_outputs(s.occ, cnt, sums))
+    assert biggest > 256 + 64, biggest                            # the heavy path WOULD have been taken
+    exp = oracle_mod.aggregate_views(per_view, s.grid_origin.astype(np.float64), s.voxel_size)
+    agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, C, "parity", DEV)
+    agg.add_views(torch.from_numpy(feats).to(DEV), torch.from_numpy(c2w), torch.from_numpy(s.intr))
+    r = agg.result()
+    assert np.array_equal(r["voxel_coords"].numpy(), exp["voxel_coords"]) and np.array_equal(r["hit_count"].numpy(), exp["hit_count"])
+    assert r["avg_feats"].numpy().tobytes() == exp["avg_feats"].tobytes()

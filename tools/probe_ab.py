@@ -15,6 +15,8 @@ from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 libs = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
 pipeline = "--pipeline" in sys.argv
 half = "--f16" in sys.argv
+# --heavy-ts=a,b,c: per library also sweep the heavy-voxel threshold (env VOXPROJ_HEAVY_T, read by the library per call; 0 = default)
+heavy_ts = next(([int(v) for v in a.split("=")[1].split(",")] for a in sys.argv if a.startswith("--heavy-ts=")), [None])
 dev = torch.device("cuda", 0)
 if "--r1" in sys.argv:      # BASELINE config 2
     n_vox, n_views, W, H, C = 80000, 100, 484, 274, 512
@@ -37,7 +39,12 @@ count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
 out = torch.zeros(n_vox + 1, C, dtype=torch.float32, device=dev)
 ref = None
 for rnd in range(3):
-    for path in libs:
+    for path, ht in [(p_, h_) for p_ in libs for h_ in heavy_ts]:
+        if ht is not None:
+            if ht:
+                os.environ["VOXPROJ_HEAVY_T"] = str(ht)
+            else:
+                os.environ.pop("VOXPROJ_HEAVY_T", None)
         voxproj_host._lib = None
         voxproj_host.LIB_PATH = path
         ws = voxproj_host.Workspace()
@@ -59,7 +66,7 @@ for rnd in range(3):
         chk = (int(count.sum().item()), float(out.double().sum().item()))
         if ref is None:
             ref = chk
-        print(f"round {rnd} {os.path.basename(path):24s} gather {p['gather_ms'] / max(p['gather_launches'], 1):.3f} ms/launch  "
+        print(f"round {rnd} {os.path.basename(path) + ('' if ht is None else f' T={ht}'):24s} gather {p['gather_ms'] / max(p['gather_launches'], 1):.3f} ms/launch  "
               f"march {p['first_hit_ms'] / max(p['first_hit_launches'], 1):.3f}  wall {ev0.elapsed_time(ev1) / (2 * NCALL):.3f} ms/call  "
               f"same result: {chk == ref}", flush=True)
         ws.release()
