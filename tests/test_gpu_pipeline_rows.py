@@ -477,3 +477,44 @@ def test_parity_aggregator_is_bit_exact_with_large_voxels_under_production_setti
     r = agg.result()
     assert np.array_equal(r["voxel_coords"].numpy(), exp["voxel_coords"]) and np.array_equal(r["hit_count"].numpy(), exp["hit_count"])
     assert r["avg_feats"].numpy().tobytes() == exp["avg_feats"].tobytes()
+
+
+def test_reference_three_script_chain_on_files(tmp_path, oracle_mod):
+    # What aggregate_voxel_features_onthefly.py:118-127,248-294 runs as sub-processes per view -- build_sparse_occupancy.py ->
+    # prepare_tensor_data.py (--max_images 1 --downsample_factor 0.5 --image_size H W) -> debug_project_features.py -- with
+    # this package's scripts of the same names, through their command-line mains and the files in between.  The final
+    # proj_output.pt must be what the oracle computes from the same inputs (occupancy builder, OpenCV-rule resize,
+    # projector, fp16 hit rows), bit for bit.
+    import build_sparse_occupancy as bso
+    import debug_project_features as dpf
+    import prepare_tensor_data as ptd
+    from oracle import resize_oracle as ro
+    s, ply, lseg, cam_json = _write_scene_files(tmp_path, n_views=2, C=16)
+    occ_pt, td_pt, out_pt = tmp_path / "ALL_occupancy.pt", tmp_path / "tensor_data.pt", tmp_path / "proj_output.pt"
+    vs, origin, _, _ = bso.extract_voxel_params(str(ply))
+    bso.main(["--voxel_ply", str(ply), "--voxel_size", repr(vs), "--grid_origin", *[repr(v) for v in origin], "--out_tensor", str(occ_pt)])
+    ptd.main(["--lseg_dir", str(lseg), "--scaled_camera_params", str(cam_json), "--occupancy", str(occ_pt), "--voxel_size", repr(vs),
+              "--grid_origin", *[repr(v) for v in origin], "--max_images", "1", "--output", str(td_pt),
+              "--image_size", "32", "48", "--downsample_factor", "0.5"])
+    dpf.main(["--tensor_data", str(td_pt), "--output", str(out_pt)])
+    got = torch.load(out_pt)
+    assert set(got) == {"projected_feats", "projected_indices"}
+    # the oracle's version of the same chain
+    occ = oracle_mod.build_occupancy(bso.read_voxel_ply(str(ply)), origin, vs)
+    assert np.array_equal(torch.load(occ_pt).numpy(), occ)
+    first = sorted(os.listdir(lseg))[0]
+    feats = ro.upsample_features(np.load(lseg / first), 32, 48)[None, None]                  # [1,1,H,W,C] float32
+    td = torch.load(td_pt)
+    assert td["encoded_2d_features"].numpy().tobytes() == feats.tobytes()
+    intr0 = td["intrinsicParams"][:, 0, :].numpy()
+    c2w0 = td["viewMatrixInv"][0, 0].numpy()
+    n_rows = int(occ.max()) + 1
+    cnt = np.zeros(n_rows, np.int32)
+    sums = np.zeros((n_rows, 16), np.float32)
+    opts = np.array([48, 32, 0.01, 10.0, vs * 0.5], np.float32)                               # DPF:167-169
+    oracle_mod.project_features(feats, occ[None].astype(np.int64), c2w0.reshape(-1), intr0, opts, np.array(origin, np.float32), vs,
+                                cnt, sums)
+    ef, ei = oracle_mod.dpf_select_outputs(occ, cnt, sums)
+    assert len(ei) > 100
+    assert np.array_equal(got["projected_indices"].numpy(), ei)
+    assert got["projected_feats"].dtype == torch.float16 and got["projected_feats"].numpy().tobytes() == ef.tobytes()
