@@ -544,6 +544,9 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
 template <int K, int VEC, int U>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
+    // Registers: 97 VGPRs = 4 wavefronts per SIMD.  Forcing 5 (<= 96, __launch_bounds__(256, 5)) was measured on one
+    // allocation: serial phases -1.0 .. -1.4 %, but pipelined +2.5 % (fp16) / +2 % (R1) / -0.4 % (fp32) -- the fifth gather
+    // wave takes the room the next call's march needs.
     // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
     // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
     // march waves of the next call that share the SIMD in pipelined mode.
