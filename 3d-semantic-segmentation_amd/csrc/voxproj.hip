@@ -63,6 +63,14 @@
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
+// the same for k_gather, whose fourth template argument says whether the launch carries the heavy-voxel role
+#define VP_DISPATCH_GATHER(MERGED, VEC_OK, C, ...)                                \
+    do {                                                                          \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather<1, 8, VP_F16_U, MERGED>), __VA_ARGS__);    \
+        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather<2, 4, 4, MERGED>), __VA_ARGS__); \
+        else if (VEC_OK) hipLaunchKernelGGL((k_gather<1, 4, 4, MERGED>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((k_gather<4, 1, 4, MERGED>), __VA_ARGS__);                  \
+    } while (0)
 
 // rows in flight per wavefront in the fp16 gather
 #ifndef VP_F16_U
@@ -272,11 +280,21 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
     const int blocks_n = (int)((n_rows - 1 + 3) / 4);
-    // heavy voxels are the first workgroups of the same launch (vp_gather.h)
+    // Heavy voxels: the first workgroups of the gather's own launch when the call has many views; a launch of their own
+    // in front of it, 16 wavefronts per voxel, when it has few (vp_gather.h)
+    const bool merged_heavy = (long long)B * V >= 8;
+    g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
     if (pipe) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
+    if (!merged_heavy) {
+        ProfSpan sp; sp.begin(3, s0);
+        VP_DISPATCH_KVU(k_gather_heavy, vec_ok, C, dim3(HEAVY_BLOCKS), dim3(GW_ALONE * 64), 0, s0, g, p);
+        sp.end();
+    }
     {
         ProfSpan sp; sp.begin(2, s0);
-        VP_DISPATCH_KVU(k_gather, vec_ok, C, dim3(HEAVY_BLOCKS + (blocks_n > 0 ? blocks_n : 0)), dim3(256), 0, s0, g, p);
+        const dim3 ggrid(g.heavy_blocks + (blocks_n > 0 ? blocks_n : 0));
+        if (merged_heavy) VP_DISPATCH_GATHER(true, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+        else VP_DISPATCH_GATHER(false, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         sp.end();
     }
     if (pipe) {

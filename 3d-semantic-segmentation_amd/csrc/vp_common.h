@@ -31,7 +31,7 @@ struct Profile {
     std::mutex mu;
     bool on = false;
     std::vector<hipEvent_t> pool;    // event pairs
-    std::vector<int> kind;           // per pair: 0 prep, 1 first_hit (+ work list, view table), 2 gather (incl. heavy voxels)
+    std::vector<int> kind;           // per pair: 0 prep, 1 first_hit (+ work list, view table), 2 gather, 3 heavy voxels' own launch (few-view calls)
     size_t used = 0;                 // pairs in use
     // returns the pair index, or -1
     int next(int k)

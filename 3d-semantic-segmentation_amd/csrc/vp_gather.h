@@ -219,6 +219,7 @@ struct GatherArgs {
     const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
     const int *n_heavy;
     int heavy_t;
+    int heavy_blocks;        // leading workgroups of k_gather that take the heavy voxels (0: k_gather_heavy does)
     const int *work;         // work list of this call: WORK_CLASSES arrays of n_rows voxel IDs, by size class (k_worklist)
     const int *work_n;       // voxels per class
     int *count;
@@ -227,7 +228,8 @@ struct GatherArgs {
     int *status;
 };
 
-constexpr int GW = 4;            // wavefronts that share one heavy voxel (= one k_gather workgroup)
+constexpr int GW_MERGED = 4;     // wavefronts that share one heavy voxel inside k_gather (= one of its workgroups)
+constexpr int GW_ALONE = 16;     // ... in k_gather_heavy, the separate launch used for calls of few views
 constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather that take the heavy voxels
 
 // views whose first ID tile is fetched together by the one-wavefront gather (1 = one view at a time)
@@ -410,7 +412,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
 // each wavefront sums its range in raster order, and the partial rows are combined through LDS in
 // wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
 // the serial order in the last bits only, well inside the 1e-4 bar).
-template <int K, int VEC, int U>
+template <int K, int VEC, int U, int GW>
 __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id, int expected,
                                    float (*part)[64 * K * VEC], int *part_found, bool whole_image)
 {
@@ -541,7 +543,9 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
             work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
 }
 
-template <int K, int VEC, int U>
+// MERGED: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of many views).  The variant without
+// that role needs one register less, which is one more wavefront per SIMD -- worth 5 % on a one-view call.
+template <int K, int VEC, int U, bool MERGED>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
     // Registers: 97 VGPRs = 4 wavefronts per SIMD.  Forcing 5 (<= 96, __launch_bounds__(256, 5)) was measured on one
@@ -551,26 +555,28 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
     // march waves of the next call that share the SIMD in pipelined mode.
     __builtin_amdgcn_s_setprio(3);
-    __shared__ __attribute__((aligned(16))) float part[GW][64 * K * VEC];
-    __shared__ int part_found[GW];
-    if (blockIdx.x < HEAVY_BLOCKS) {
+    __shared__ __attribute__((aligned(16))) float part[MERGED ? GW_MERGED : 1][MERGED ? 64 * K * VEC : 1];
+    __shared__ int part_found[GW_MERGED];
+    if (MERGED && (int)blockIdx.x < g.heavy_blocks) {
         // Heavy role: the first workgroups of the grid -- so they start before anything else, the longest jobs first --
         // take the voxels that collected more than heavy_t pixels in this call, one voxel per workgroup at a time, the
         // four wavefronts splitting each view's box rows (gather_voxel_block).  First the search boxes; on a pixel-count
         // mismatch nothing was stored: redo over whole images.
         const int n_heavy = *g.n_heavy;
-        for (int h = blockIdx.x; h < n_heavy; h += HEAVY_BLOCKS) {
+        for (int h = blockIdx.x; h < n_heavy; h += g.heavy_blocks) {
             const int id = g.heavy_list[h];
             const int expected = g.cnt_call[id];
-            if (!gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, false)) {
-                if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-                gather_voxel_block<K, VEC, U>(g, p, id, expected, part, part_found, true);
+            if constexpr (MERGED) {
+                if (!gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, false)) {
+                    if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+                    gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, true);
+                }
             }
         }
         return;
     }
     const int lane = threadIdx.x & 63;
-    long long w = (long long)(blockIdx.x - HEAVY_BLOCKS) * 4 + (threadIdx.x >> 6);
+    long long w = (long long)((int)blockIdx.x - (MERGED ? g.heavy_blocks : 0)) * 4 + (threadIdx.x >> 6);
     int id = 0;
 #pragma unroll
     for (int k = WORK_CLASSES - 1; k >= 0; k--) {
@@ -581,6 +587,26 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     if (id == 0) return;
     const int expected = g.cnt_call[id];
     gather_voxel_wave<K, VEC, U, VP_GATHER_G(VEC)>(g, p, id, expected, lane);
+}
+
+// Calls of few views (the drop-in module's one view per call): the heavy voxels are few but each is a large share of a
+// short launch, so they get a launch of their own with 16 wavefronts per voxel, in front of k_gather on the same stream
+// (measured, one R2 view per blocking call: 0.372 ms this way, 0.392 ms with 4 wavefronts per voxel inside k_gather; with
+// 16 or 32 views per call the merged form is 2-4 % faster, vp_gather.h above).
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(GW_ALONE * 64) void k_gather_heavy(GatherArgs g, Params p)
+{
+    __shared__ __attribute__((aligned(16))) float part[GW_ALONE][64 * K * VEC];
+    __shared__ int part_found[GW_ALONE];
+    const int n_heavy = *g.n_heavy;
+    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const int id = g.heavy_list[h];
+        const int expected = g.cnt_call[id];
+        if (!gather_voxel_block<K, VEC, U, GW_ALONE>(g, p, id, expected, part, part_found, false)) {
+            if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+            gather_voxel_block<K, VEC, U, GW_ALONE>(g, p, id, expected, part, part_found, true);
+        }
+    }
 }
 
 }  // namespace

@@ -175,8 +175,8 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
  * vp_profile_enable(1) starts recording for subsequent vp_project_features calls of this process;
  * vp_profile_read synchronises the recorded events and returns, per kernel group, the summed
  * milliseconds and the number of launches: [0] = table preparation (memsets, occupancy tables, view
- * table), [1] = k_first_hit + work list + view table (phase 1), [2] = k_gather (phase 2, heavy voxels included), [3] = unused
- * since ABI v2 (always 0: heavy voxels are part of the k_gather launch); then clears
+ * table), [1] = k_first_hit + work list + view table (phase 1), [2] = k_gather (phase 2; includes the heavy voxels when the call
+ * has 8 or more views), [3] = k_gather_heavy (the heavy voxels' own launch in calls of fewer views); then clears
  * the record.
  */
 int vp_profile_enable(int on);
