@@ -543,14 +543,15 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
             work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
 }
 
-// MERGED: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of many views).  The variant without
-// that role needs one register less, which is one more wavefront per SIMD -- worth 5 % on a one-view call.
+// MERGED = true: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of 8 or more views); 97 VGPRs,
+// i.e. 4 wavefronts per SIMD -- in pipelined mode a gain, because a fifth gather wave would take the room the next call's
+// march needs (forcing <= 96 registers with __launch_bounds__(256, 5), one allocation: pipelined +2.5 % fp16 / +2 % R1 /
+// -0.4 % fp32; serial phases -1.0 .. -1.4 %).
+// MERGED = false: without that role the kernel needs 96 VGPRs = 5 wavefronts per SIMD, worth 5 % on a one-view call
+// (0.372 vs 0.392 ms per blocking R2 call); the heavy voxels of such calls go to k_gather_heavy below.
 template <int K, int VEC, int U, bool MERGED>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
-    // Registers: 97 VGPRs = 4 wavefronts per SIMD.  Forcing 5 (<= 96, __launch_bounds__(256, 5)) was measured on one
-    // allocation: serial phases -1.0 .. -1.4 %, but pipelined +2.5 % (fp16) / +2 % (R1) / -0.4 % (fp32) -- the fifth gather
-    // wave takes the room the next call's march needs.
     // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
     // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
     // march waves of the next call that share the SIMD in pipelined mode.
@@ -589,10 +590,9 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     gather_voxel_wave<K, VEC, U, VP_GATHER_G(VEC)>(g, p, id, expected, lane);
 }
 
-// Calls of few views (the drop-in module's one view per call): the heavy voxels are few but each is a large share of a
-// short launch, so they get a launch of their own with 16 wavefronts per voxel, in front of k_gather on the same stream
-// (measured, one R2 view per blocking call: 0.372 ms this way, 0.392 ms with 4 wavefronts per voxel inside k_gather; with
-// 16 or 32 views per call the merged form is 2-4 % faster, vp_gather.h above).
+// Calls of few views (the drop-in module's one view per call): the heavy voxels are few, each a large share of a short
+// launch: a launch of their own with 16 wavefronts per voxel, in front of k_gather<..., false> on the same stream.  (With 16
+// or 32 views per call the merged form above is 2-4 % faster per call.)
 template <int K, int VEC, int U>
 __global__ __launch_bounds__(GW_ALONE * 64) void k_gather_heavy(GatherArgs g, Params p)
 {

@@ -518,3 +518,41 @@ def test_reference_three_script_chain_on_files(tmp_path, oracle_mod):
     assert len(ei) > 100
     assert np.array_equal(got["projected_indices"].numpy(), ei)
     assert got["projected_feats"].dtype == torch.float16 and got["projected_feats"].numpy().tobytes() == ef.tobytes()
+
+
+def test_reference_colour_script_chain_on_files(tmp_path, oracle_mod):
+    # aggregate_voxel_colors_onthefly.py:103-121 per view: prepare_tensor_data_color.py -> debug_project_colors.py, through
+    # this package's command-line mains and the tensor_data.pt (with its `image` key, PTDC:144) in between
+    import json
+
+    from PIL import Image
+
+    import debug_project_colors as dpc
+    import prepare_tensor_data_color as ptdc
+    from synthetic_scene import make_scene
+    s = make_scene(1500, 1, 60, 40, seed=93, room=(5.0, 4.0, 2.4))
+    rng = np.random.default_rng(93)
+    lseg, images = tmp_path / "features", tmp_path / "images"
+    lseg.mkdir(); images.mkdir()
+    np.save(lseg / "IMG000.npy", rng.standard_normal((4, 10, 15)).astype(np.float16))
+    img = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    Image.fromarray(img).save(images / "IMG000.png")
+    c2w = s.c2w[0].astype(np.float64)
+    R = c2w[:3, :3].T
+    cams = {"images": {"0": {"name": "IMG000", "camera_id": 1, "R": R.tolist(), "tvec": (-R @ c2w[:3, 3]).tolist()}},
+            "cameras": {"1": {"params": [float(x) for x in s.intr]}}}
+    (tmp_path / "cams.json").write_text(json.dumps(cams))
+    torch.save(torch.from_numpy(s.occ), tmp_path / "occ.pt")
+    td, out = tmp_path / "tensor_data.pt", tmp_path / "proj_output.pt"
+    ptdc.main(["--lseg_dir", str(lseg), "--scaled_camera_params", str(tmp_path / "cams.json"), "--occupancy", str(tmp_path / "occ.pt"),
+               "--voxel_size", repr(s.voxel_size), "--grid_origin", *[repr(float(v)) for v in s.grid_origin], "--max_images", "1",
+               "--output", str(td), "--images_dir", str(images)])
+    dpc.main(["--tensor_data", str(td), "--output", str(out)])
+    got = torch.load(out)
+    assert set(got) == {"projected_colors", "projected_indices", "pixel_indices"}
+    d = torch.load(td, weights_only=False)
+    col, zyx, uv = oracle_mod.rgb_project(s.occ, d["viewMatrixInv"][0, 0].numpy(), d["intrinsicParams"][0, 0].numpy(),
+                                          d["grid_origin"].numpy(), d["voxel_size"], d["image"])
+    assert len(zyx) > 100 and np.array_equal(d["image"], img)
+    assert np.array_equal(got["projected_indices"].numpy(), zyx) and np.array_equal(got["pixel_indices"].numpy(), uv)
+    assert got["projected_colors"].numpy().tobytes() == col.tobytes()
