@@ -503,18 +503,34 @@ int vp_upsample_features(const void *src_chw, int src_is_f16, int C, int h, int 
     // cv::resize derives the scale from the destination size: inv_scale = dsize / ssize, scale = 1 / inv_scale
     const double scale_x = 1.0 / ((double)W / (double)w), scale_y = 1.0 / ((double)H / (double)h);
     const unsigned ublocks = (unsigned)(((long long)H * W + 4 * UPS_PIX - 1) / (4 * UPS_PIX));
-#define VP_UPS(TS_, TD_, VEC_) hipLaunchKernelGGL((k_upsample_hwc<TS_, TD_, VEC_>), dim3(ublocks), dim3(256), 0, stream, \
+#define VP_UPS1(TS_, TD_, VEC_, NV_) hipLaunchKernelGGL((k_upsample_hwc<TS_, TD_, VEC_, NV_>), dim3(ublocks), dim3(256), 0, stream, \
         (const TS_ *)workspace, (TD_ *)dst_hwc, C, h, w, H, W, scale_x, scale_y)
+    // channel groups a lane owns: the register window of the kernel is instantiated for 1, 2 or 4 of them
+#define VP_UPS(TS_, TD_, VEC_)                                           \
+    do {                                                                 \
+        const int groups_ = (C + 64 * (VEC_) - 1) / (64 * (VEC_));      \
+        if (groups_ <= 1) VP_UPS1(TS_, TD_, VEC_, 1);                    \
+        else if (groups_ <= 2) VP_UPS1(TS_, TD_, VEC_, 2);               \
+        else if (groups_ <= 4) VP_UPS1(TS_, TD_, VEC_, 4);               \
+        else VP_UPS1(TS_, TD_, VEC_, 0);                                 \
+    } while (0)
     const bool al16 = (((uintptr_t)workspace | (uintptr_t)dst_hwc) & 15) == 0;
     if (src_is_f16) {
-        hipLaunchKernelGGL((k_chw_to_hwc<_Float16>), tgrid, dim3(256), 0, stream, (const _Float16 *)src_chw, (_Float16 *)workspace, C, P);
+        if ((((uintptr_t)src_chw | (uintptr_t)workspace) & 15) == 0 && P % 8 == 0 && C % 8 == 0)
+            hipLaunchKernelGGL((k_chw_to_hwc_v16<_Float16>), tgrid, dim3(256), 0, stream, (const _Float16 *)src_chw, (_Float16 *)workspace, C, P);
+        else
+            hipLaunchKernelGGL((k_chw_to_hwc<_Float16>), tgrid, dim3(256), 0, stream, (const _Float16 *)src_chw, (_Float16 *)workspace, C, P);
         const bool v8 = al16 && C % 8 == 0;
         if (dst_is_f16) { if (v8) VP_UPS(_Float16, _Float16, 8); else VP_UPS(_Float16, _Float16, 1); }
         else { if (v8) VP_UPS(_Float16, float, 8); else VP_UPS(_Float16, float, 1); }
     } else {
-        hipLaunchKernelGGL((k_chw_to_hwc<float>), tgrid, dim3(256), 0, stream, (const float *)src_chw, (float *)workspace, C, P);
+        if ((((uintptr_t)src_chw | (uintptr_t)workspace) & 15) == 0 && P % 4 == 0 && C % 4 == 0)
+            hipLaunchKernelGGL((k_chw_to_hwc_v16<float>), tgrid, dim3(256), 0, stream, (const float *)src_chw, (float *)workspace, C, P);
+        else
+            hipLaunchKernelGGL((k_chw_to_hwc<float>), tgrid, dim3(256), 0, stream, (const float *)src_chw, (float *)workspace, C, P);
         if (al16 && C % 4 == 0) VP_UPS(float, float, 4); else VP_UPS(float, float, 1);
     }
+#undef VP_UPS1
 #undef VP_UPS
     VP_HIP(hipGetLastError());
     return VP_OK;

@@ -26,10 +26,15 @@ namespace {
 // OpenCV's SIMD builds may fuse the vertical pass (v_muladd); that build-dependent last-bit choice is outside the spec,
 // see DESIGN.md.  oracle/resize_oracle.py restates the same arithmetic in numpy float32.
 // ------------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T>
+struct VecOf<T, 1> { typedef T type; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_chw_to_hwc(const T *__restrict__ src, T *__restrict__ dst, int C, long long P)
 {
-    // src [C,P] -> dst [P,C]; 64x64 tile, 256 threads: 16 rows of 64 per pass
+    // src [C,P] -> dst [P,C]; 64x64 tile, 256 threads: 16 rows of 64 per pass (any shape; element-wise accesses)
     __shared__ T tile[64][65];
     const long long p0 = (long long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
@@ -47,18 +52,47 @@ __global__ __launch_bounds__(256) void k_chw_to_hwc(const T *__restrict__ src, T
     }
 }
 
+// The same transpose with 16-byte accesses on both sides (P and C multiples of E = 16 / sizeof(T), 16-byte aligned
+// pointers): a lane reads E consecutive positions of one channel and writes E consecutive channels of one position, so
+// a 64x64 tile moves with 1/E of the memory instructions of the element-wise kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void k_chw_to_hwc_v16(const T *__restrict__ src, T *__restrict__ dst, int C, long long P)
+{
+    constexpr int E = 16 / (int)sizeof(T);          // elements per 16 bytes: 8 (binary16) or 4 (float)
+    constexpr int SEG = 64 / E;                     // 16-byte segments per 64-element tile row
+    constexpr int PITCH = 64 + E;                   // keeps every row of the tile 16-byte aligned and staggers the banks
+    typedef typename VecOf<T, E>::type V;
+    __shared__ __attribute__((aligned(16))) T tile[64 * PITCH];     // [channel][position]
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int seg = threadIdx.x % SEG, row = threadIdx.x / SEG;     // 256 / SEG rows per pass
+    for (int r = row; r < 64; r += 256 / SEG) {
+        const int c = c0 + r;
+        const long long p = p0 + seg * E;
+        if (c < C && p < P) *reinterpret_cast<V *>(&tile[r * PITCH + seg * E]) = *reinterpret_cast<const V *>(src + (long long)c * P + p);
+    }
+    __syncthreads();
+    for (int r = row; r < 64; r += 256 / SEG) {                      // now r = position inside the tile, seg = channel segment
+        const long long p = p0 + r;
+        const int c = c0 + seg * E;
+        if (c < C && p < P) {
+            V v;
+#pragma unroll
+            for (int e = 0; e < E; e++) v[e] = tile[(seg * E + e) * PITCH + r];
+            *reinterpret_cast<V *>(dst + p * C + c) = v;
+        }
+    }
+}
+
 // one wavefront per output pixel, lanes over channels: VEC consecutive channels per lane (16-byte loads when
 // VEC * sizeof(TS) == 16), consecutive lanes = consecutive channel groups, so every source and destination row moves as
 // whole contiguous lines
-template <typename T, int N>
-struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
-template <typename T>
-struct VecOf<T, 1> { typedef T type; };
-
 constexpr int UPS_PIX = 8;   // consecutive output pixels per wavefront (fewer, longer-lived waves: the launch rate of
                              // one-pixel waves, not memory, bounded the first version of this kernel)
 
-template <typename TS, typename TD, int VEC>
+// NV > 0: the lane owns NV channel groups of 64*VEC (C <= 64*VEC*NV) and keeps the window in registers; NV = 0: any C, every
+// tap loaded where it is used.
+template <typename TS, typename TD, int VEC, int NV_>
 __global__ __launch_bounds__(256) void k_upsample_hwc(const TS *__restrict__ src, TD *__restrict__ dst, int C, int h, int w,
                                                       int H, int W, double scale_x, double scale_y)
 {
@@ -67,7 +101,13 @@ __global__ __launch_bounds__(256) void k_upsample_hwc(const TS *__restrict__ src
     const int lane = threadIdx.x & 63;
     typedef typename VecOf<TS, VEC>::type VS;
     typedef typename VecOf<TD, VEC>::type VD;
-#pragma unroll 2
+    // Sliding window over the source columns: consecutive output pixels of a row use the same source column or the next
+    // one (up-sampling), so the window's right column becomes its left column and only one new column (two rows) is
+    // loaded -- ~14 row loads per 8 pixels instead of 32.  All of it is wave-uniform control flow.
+    constexpr int NV = NV_ > 0 ? NV_ : 1;
+    constexpr bool small = NV_ > 0;
+    VS l0[NV], l1[NV], r0v[NV], r1v[NV];
+    int cur_dy = -1, cur_sx = -2;
     for (int q = 0; q < UPS_PIX; q++) {
         const long long pix = pix0 + q;
         if (pix >= HW) return;
@@ -85,27 +125,47 @@ __global__ __launch_bounds__(256) void k_upsample_hwc(const TS *__restrict__ src
         const bool two = sx < w - 1;      // at the right border OpenCV copies S[sx] (x >= xmax: D[dx] = S[sx] * 1)
         const TS *s00 = src + ((long long)sy0 * w + sx) * C, *s10 = src + ((long long)sy1 * w + sx) * C;
         TD *o = dst + pix * C;
-        for (int c = lane * VEC; c < C; c += 64 * VEC) {
-            const VS p00 = *reinterpret_cast<const VS *>(s00 + c), p10 = *reinterpret_cast<const VS *>(s10 + c);
-            VS p01 = p00, p11 = p10;
-            if (two) {
-                p01 = *reinterpret_cast<const VS *>(s00 + C + c);
-                p11 = *reinterpret_cast<const VS *>(s10 + C + c);
-            }
-            VD res;
+        if (small) {
+            const bool slide = (dy == cur_dy) && (sx == cur_sx + 1);
+            if (dy != cur_dy || sx != cur_sx) {
 #pragma unroll
-            for (int e = 0; e < VEC; e++) {
-                float q00, q01, q10, q11;
-                if constexpr (VEC == 1) { q00 = (float)p00; q01 = (float)p01; q10 = (float)p10; q11 = (float)p11; }
-                else { q00 = (float)p00[e]; q01 = (float)p01[e]; q10 = (float)p10[e]; q11 = (float)p11[e]; }
-                const float r0 = two ? q00 * a0 + q01 * a1 : q00 * 1.f;
-                const float r1 = two ? q10 * a0 + q11 * a1 : q10 * 1.f;
-                const float v = r0 * b0 + r1 * b1;
-                const TS back = (TS)v;                   // PTD:126 arr_upsampled.astype(arr.dtype)
-                if constexpr (VEC == 1) res = (TD)back;  // PTD:152 .float() (exact) or kept in the file's dtype
-                else res[e] = (TD)back;
+                for (int k = 0; k < NV; k++) {
+                    const int c = (k * 64 + lane) * VEC;
+                    if (c < C) {
+                        if (slide) { l0[k] = r0v[k]; l1[k] = r1v[k]; }
+                        else { l0[k] = *reinterpret_cast<const VS *>(s00 + c); l1[k] = *reinterpret_cast<const VS *>(s10 + c); }
+                        if (two) { r0v[k] = *reinterpret_cast<const VS *>(s00 + C + c); r1v[k] = *reinterpret_cast<const VS *>(s10 + C + c); }
+                    }
+                }
+                cur_dy = dy; cur_sx = sx;
             }
-            __builtin_nontemporal_store(res, reinterpret_cast<VD *>(o + c));   // written once, read by another kernel later
+        }
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            for (int c = (k * 64 + lane) * VEC; c < C; c += 64 * VEC * NV) {
+                VS p00, p10, p01, p11;
+                if (small) { p00 = l0[k]; p10 = l1[k]; p01 = two ? r0v[k] : p00; p11 = two ? r1v[k] : p10; }
+                else {
+                    p00 = *reinterpret_cast<const VS *>(s00 + c); p10 = *reinterpret_cast<const VS *>(s10 + c);
+                    p01 = p00; p11 = p10;
+                    if (two) { p01 = *reinterpret_cast<const VS *>(s00 + C + c); p11 = *reinterpret_cast<const VS *>(s10 + C + c); }
+                }
+                VD res;
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    float q00, q01, q10, q11;
+                    if constexpr (VEC == 1) { q00 = (float)p00; q01 = (float)p01; q10 = (float)p10; q11 = (float)p11; }
+                    else { q00 = (float)p00[e]; q01 = (float)p01[e]; q10 = (float)p10[e]; q11 = (float)p11[e]; }
+                    const float r0 = two ? q00 * a0 + q01 * a1 : q00 * 1.f;
+                    const float r1 = two ? q10 * a0 + q11 * a1 : q10 * 1.f;
+                    const float v = r0 * b0 + r1 * b1;
+                    const TS back = (TS)v;                   // PTD:126 arr_upsampled.astype(arr.dtype)
+                    if constexpr (VEC == 1) res = (TD)back;  // PTD:152 .float() (exact) or kept in the file's dtype
+                    else res[e] = (TD)back;
+                }
+                __builtin_nontemporal_store(res, reinterpret_cast<VD *>(o + c));   // written once, read by another kernel later
+                if (small) break;                            // one group per k when the window holds the whole row
+            }
         }
     }
 }
