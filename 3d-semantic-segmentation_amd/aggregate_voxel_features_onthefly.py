@@ -222,6 +222,60 @@ def write_feature_ply(path, xyz_f32, avg_feats_f16):
             f.write(line + "\n")
 
 
+class FeatureFeeder:
+    """Feeds the .npy feature maps to the GPU ahead of the projector (the reference re-reads each map from disk three times
+    per view through its sub-processes, AGG:248-294).  Worker threads read a file up to ``depth`` views ahead AND stage it in
+    a pinned host buffer (file reads and the staging copy release the GIL); the consumer's thread only issues the
+    host-to-device copy on a copy stream of its own.  Reading view k+2, copying view k+1 over PCIe (3.6 ms for a 199 MB
+    map) and projecting view k then overlap.  Iterating yields ``(index, path, device_tensor [C,h,w])`` in file order; the
+    tensor is ready on torch's current stream.  ``depth = 0`` reads and copies synchronously (same results)."""
+
+    def __init__(self, paths, device, depth=3):
+        self.paths, self.dev, self.depth = list(paths), torch.device(device), int(depth)
+
+    def __iter__(self):
+        if self.depth <= 0:
+            for i, p in enumerate(self.paths):
+                yield i, p, torch.from_numpy(np.ascontiguousarray(np.load(p))).to(self.dev)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        nbuf = self.depth + 2
+        pinned, copied = [None] * nbuf, [None] * nbuf          # staging buffers and the event of the copy that last read each
+
+        def stage(i):
+            # memory-mapped: the one pass over the file's bytes is the copy into the pinned buffer
+            import warnings
+            m = np.load(self.paths[i], mmap_mode="r")
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                  # torch warns about the read-only map; it is only read
+                arr = torch.from_numpy(np.asarray(m)) if m.flags.c_contiguous else torch.from_numpy(np.ascontiguousarray(m))
+            b = i % nbuf
+            if copied[b] is not None:
+                copied[b].synchronize()                          # view i - nbuf has left this buffer
+            if pinned[b] is None or pinned[b].shape != arr.shape or pinned[b].dtype != arr.dtype:
+                pinned[b] = torch.empty(arr.shape, dtype=arr.dtype, pin_memory=True)
+            pinned[b].copy_(arr)
+            return pinned[b]
+
+        copy_stream = torch.cuda.Stream(self.dev)
+        with ThreadPoolExecutor(max_workers=min(self.depth, 4)) as pool:
+            pending = [pool.submit(stage, i) for i in range(min(self.depth, len(self.paths)))]
+            for i, p in enumerate(self.paths):
+                host = pending.pop(0).result()
+                with torch.cuda.stream(copy_stream):
+                    d = torch.empty(host.shape, dtype=host.dtype, device=self.dev)
+                    d.copy_(host, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                copied[i % nbuf] = ev
+                if i + self.depth < len(self.paths):             # submitted only now: its buffer's previous copy is recorded
+                    pending.append(pool.submit(stage, i + self.depth))
+                cur = torch.cuda.current_stream(self.dev)
+                cur.wait_event(ev)
+                d.record_stream(cur)                             # allocated on the copy stream, consumed on this one
+                yield i, p, d
+
+
 def _image_size(entry, cams, images_dir, name):
     """(H_orig, W_orig) of a view: the reference reads the image file (AGG:210-214); the camera JSON's
     width/height are used when the image is not there."""
@@ -250,6 +304,8 @@ def main(argv=None):
     ap.add_argument("--views_per_call", type=int, default=8, help="fast mode: views per projector call")
     ap.add_argument("--half_features", action="store_true", help="fast mode: keep the (fp16-valued) feature maps in "
                     "fp16 on the GPU (vp_project_features_f16): half the HBM traffic, identical results")
+    ap.add_argument("--prefetch", type=int, default=3, help="feature files read ahead of the GPU by worker threads and "
+                    "copied over PCIe on a copy stream (0 = read and copy synchronously)")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -282,15 +338,18 @@ def main(argv=None):
     batch_f, batch_c, batch_intr = [], [], None
     from view_sharding import views_of_rank
     mine = [feature_files[i] for i in views_of_rank(len(feature_files), rank, world)]
-    for k, fpath in enumerate(mine):
+    usable = [f for f in mine if by_name.get(os.path.basename(f)[:-4]) is not None]
+    for f in mine:
+        if by_name.get(os.path.basename(f)[:-4]) is None:
+            print(f"[ERROR] No camera entry for {os.path.basename(f)[:-4]}")
+    position = {f: k for k, f in enumerate(mine)}                  # idx counts every file, as AGG:316 does
+    for _, fpath, raw in FeatureFeeder(usable, dev, args.prefetch):
+        k = position[fpath]
         name = os.path.basename(fpath)[:-4]
-        entry = by_name.get(name)
-        if entry is None:
-            print(f"[ERROR] No camera entry for {name}")
-            continue
+        entry = by_name[name]
         H0, W0 = _image_size(entry, cams, args.images_dir, name)
         H_new, W_new = int(H0 * args.downsample_factor), int(W0 * args.downsample_factor)          # AGG:215
-        feats = ptd.upsample_features(np.load(fpath), (H_new, W_new), device=dev,                  # PTD:115-127
+        feats = ptd.upsample_features(raw, (H_new, W_new), device=dev,                             # PTD:115-127
                                       keep_dtype=(args.half_features and args.mode == "fast"))
         intr, c2w = ptd.camera_for(entry, cams, args.downsample_factor)                            # PTD:132-172
         if agg is None:

@@ -293,7 +293,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     {
         ProfSpan sp; sp.begin(2, s0);
         const dim3 ggrid(g.heavy_blocks + (blocks_n > 0 ? blocks_n : 0));
-        if (merged_heavy) VP_DISPATCH_GATHER(true, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+        if (ggrid.x == 0) { /* n_rows == 1: only the dummy row 0, nothing to gather */ }
+        else if (merged_heavy) VP_DISPATCH_GATHER(true, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         else VP_DISPATCH_GATHER(false, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         sp.end();
     }

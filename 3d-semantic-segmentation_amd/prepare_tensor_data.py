@@ -59,6 +59,12 @@ def upsample_features(arr, size=None, device="cpu", keep_dtype=False, out=None):
     with ``keep_dtype``, in the file's own dtype (fp16 for LSeg features) -- the values are the same because
     PTD:126 casts the resized map back to the file's dtype before widening it.  A change of size runs on the GPU
     (``device`` must be a CUDA device then; the result stays there unless ``device`` says "cpu" -- no: it raises)."""
+    if isinstance(arr, torch.Tensor) and arr.is_cuda:              # already on the device (the aggregator's feeder)
+        import voxproj_host
+        t = arr if arr.dtype in (torch.float16, torch.float32) else arr.float()
+        C, h, w = t.shape
+        H, W = (int(v) for v in size) if size is not None else (h, w)
+        return voxproj_host.upsample_features(t, H, W, keep_dtype=keep_dtype, out=out)
     arr = np.ascontiguousarray(arr)
     if arr.dtype not in (np.float16, np.float32):
         arr = arr.astype(np.float32)

@@ -780,3 +780,17 @@ def test_reuse_accel_on_a_workspace_without_tables_is_refused():
     cnt2, out2 = torch.zeros(n_rows + 7, dtype=torch.int32, device=dev), torch.zeros(n_rows + 7, 8, device=dev)
     with pytest.raises(voxproj_host.VoxprojError, match="VP_FLAG_REUSE_ACCEL"):                                    # other n_rows
         voxproj_host.project_features_raw(feats_t, occ_t, *args, cnt2, out2, *tail, workspace=ws, reuse_accel=True)
+
+
+def test_grid_without_voxels_and_single_row_outputs(oracle_mod):
+    # an empty occupancy grid with outputs of one row (max_id + 1 = 1, DPF:158-159): nothing to march into, nothing to
+    # gather -- the call must simply return and leave the dummy row untouched, for one view and for many
+    for V in (1, 9):
+        feats = np.random.default_rng(V).standard_normal((1, V, 8, 12, 4)).astype(np.float32)
+        occ = np.zeros((1, 5, 6, 7), np.int64)
+        count_t = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out_t = torch.full((1, 4), 3.5, device=DEV)
+        c2w = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))
+        _gpu_call(feats, occ, c2w, np.array([10, 10, 6, 4], np.float32), np.array([12, 8, 0.01, 10.0, 0.05], np.float32),
+                  np.zeros(3, np.float32), 0.1, count_t, out_t)
+        assert int(count_t[0]) == 0 and bool((out_t == 3.5).all())
