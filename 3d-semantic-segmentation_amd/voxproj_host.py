@@ -450,6 +450,60 @@ def aggregate_view_f16(view_sum, view_count, run16, views, first_view, view_inde
     check(fn(key[0], key[1], key[2], key[3], key[4], int(view_index), key[5] + 4 * int(flag_index), n_rows, C, stream))
 
 
+class _ContiguousDeviceMemory:
+    """Owner of one hipExtMallocWithFlags(hipDeviceMallocContiguous) allocation, exported to torch through the CUDA array
+    interface (torch keeps this object alive for as long as a tensor views the memory; freeing happens here)."""
+
+    _hip = None
+
+    def __init__(self, nbytes, shape, typestr):
+        cls = _ContiguousDeviceMemory
+        if cls._hip is None:
+            cls._hip = ctypes.CDLL("libamdhip64.so")
+            cls._hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+            cls._hip.hipExtMallocWithFlags.restype = ctypes.c_int
+            cls._hip.hipFree.argtypes = [ctypes.c_void_p]
+        p = ctypes.c_void_p()
+        rc = cls._hip.hipExtMallocWithFlags(ctypes.byref(p), max(int(nbytes), 256), 0x4)      # hipDeviceMallocContiguous
+        if rc != 0 or not p.value:
+            raise MemoryError(f"hipExtMallocWithFlags(hipDeviceMallocContiguous, {nbytes} bytes) failed: hip error {rc}")
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (self.ptr, False),
+                                         "version": 2}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._hip.hipFree(ctypes.c_void_p(self.ptr))        # hipFree waits for the device to be done with it
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def resident_empty(shape, dtype, device, fallback=True):
+    """An uninitialised CUDA tensor for a long-lived, heavily gathered buffer (the resident feature maps, the output rows)
+    in PHYSICALLY CONTIGUOUS device memory (hipExtMallocWithFlags, hipDeviceMallocContiguous).  An experiment on the
+    placement spread of DESIGN.md section 4 (tools/probe_contig.py): inside one process a 17 GB pool re-allocated this way
+    kept one speed level (2.700-2.705 ms per 16-view launch, against 2.72-3.09 ms over plain re-allocations), but a 35 GB
+    pool showed no difference and the spread between processes stayed -- so nothing uses it by default (bench.py --alloc
+    contiguous).  With ``fallback`` a failed contiguous allocation (no contiguous range that large) falls back to torch's
+    allocator.  Returns (tensor, "contiguous" | "default")."""
+    import torch
+    dev = torch.device(device)
+    typestr = {torch.float32: "<f4", torch.float16: "<f2", torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+    n = 1
+    for v in shape:
+        n *= int(v)
+    try:
+        with torch.cuda.device(dev):
+            mem = _ContiguousDeviceMemory(n * torch.empty((), dtype=dtype).element_size(), shape, typestr)
+            return torch.as_tensor(mem, device=dev), "contiguous"
+    except (MemoryError, OSError):
+        if not fallback:
+            raise
+        return torch.empty(tuple(int(v) for v in shape), dtype=dtype, device=dev), "default"
+
+
 def stream_read_gbs(buf, repeats=3):
     """Measured streaming-read rate (GB/s) of this GPU over the float32 CUDA tensor ``buf`` (non-temporal loads)."""
     import torch

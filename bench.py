@@ -74,6 +74,12 @@ def parse():
                     help="1 (default) = take the first allocation of the resident feature pool and the output rows as it "
                          "comes; N > 1 = opt-in placement search: allocate N times during the untimed set-up, keep the "
                          "placement with the fastest pass (every try is reported in the JSON line)")
+    ap.add_argument("--alloc", default="default", choices=("contiguous", "default"),
+                    help="how this job allocates its resident buffers (feature pool, output rows): default = torch's allocator "
+                         "(plain hipMalloc); contiguous = physically contiguous device memory (hipExtMallocWithFlags, "
+                         "hipDeviceMallocContiguous; falls back to the plain allocator if no such range is free) -- an experiment "
+                         "on the placement spread, DESIGN.md section 4: it pins a 17 GB pool to one speed level inside a process, "
+                         "but does not remove the spread between processes")
     ap.add_argument("--no-overlap-reduce", action="store_true",
                     help="multi-GPU: wait for each pass's all-reduce before starting the next pass (default: the "
                          "all-reduce of pass k runs on RCCL's stream while pass k+1 is projected into a second buffer)")
@@ -456,12 +462,22 @@ def main():
 
     esize = 4 if a.dtype == "f32" else 2
 
+    alloc_kind = {}
+
+    def resident(shape, dtype, what):
+        if a.alloc == "contiguous":
+            t, kind = voxproj_host.resident_empty(shape, dtype, dev)
+        else:
+            t, kind = torch.empty(shape, dtype=dtype, device=dev), "default"
+        alloc_kind[what] = kind
+        return t
+
     def alloc_pool():
         if a.dtype == "f32":
-            f = torch.empty((1, pool, H, W, C), dtype=torch.float32, device=dev)
+            f = resident((1, pool, H, W, C), torch.float32, "feature_pool")
             make_features_torch(pool, H, W, C, dev, seed=0, out=f[0])
         else:
-            f = torch.empty((1, pool, H, W, C), dtype=torch.float16, device=dev)
+            f = resident((1, pool, H, W, C), torch.float16, "feature_pool")
             for v in range(pool):
                 f[0, v] = make_features_torch(1, H, W, C, dev, seed=v)[0].half()
         return f
@@ -501,8 +517,8 @@ def main():
     parked, best = [], None
     for t in range(max(1, a.pool_tries)):
         f_try = alloc_pool()
-        c_try = torch.zeros(n_rows, dtype=torch.int32, device=dev)
-        o_try = torch.zeros(n_rows, C, dtype=torch.float32, device=dev)
+        c_try = resident((n_rows,), torch.int32, "hit_counts").zero_()
+        o_try = resident((n_rows, C), torch.float32, "output_rows").zero_()
         feats = f_try
         ms = 0.0
         for rep in range(2):
@@ -519,6 +535,7 @@ def main():
             best = (ms, t, f_try, c_try, o_try)
         parked.append((f_try, c_try, o_try))
     placement["picked"] = best[1]
+    placement["allocation"] = dict(alloc_kind)
     feats, count, out = best[2], best[3], best[4]
     del parked, best, f_try, c_try, o_try
     torch.cuda.empty_cache()
@@ -528,7 +545,7 @@ def main():
     # region ends
     bufs = [(out, count)]
     if dist is not None and not a.no_overlap_reduce:
-        bufs.append((torch.zeros_like(out), torch.zeros_like(count)))
+        bufs.append((resident((n_rows, C), torch.float32, "output_rows_2").zero_(), resident((n_rows,), torch.int32, "hit_counts_2").zero_()))
     inflight = [None] * len(bufs)
     state = {"k": 0}
 
