@@ -224,7 +224,8 @@ def _max_over_ranks(dist, dt, dev):
 def bench_colors(a, dev, rank, world, dist):
     """BASELINE config 5 (R4): the RGB path -- 500 000 voxels x 1000 views, uint8 [1168,1752,3] images, voxel-driven nearest
     pixel, no occlusion (debug_project_colors.py:54-81 + aggregate_voxel_colors_onthefly.py:134-140).  One STEP = all 1000
-    views through vp_project_colors in calls of --chunk views (a pool of distinct images is cycled).  Three bytes are
+    views through vp_project_colors in calls of --chunk views (default: all of a rank's views in one call; 1000 images are
+    6.1 GB).  Three bytes are
     gathered per voxel-view, so the kernel is latency / float64-ALU bound: the line carries the roofline object the
     contract asks for, with the honest fraction, and makes no roofline claim."""
     import voxproj_host
@@ -233,7 +234,7 @@ def bench_colors(a, dev, rank, world, dist):
     N, V, W, H = 500000, a.views or 1000, 1752, 1168
     s = make_scene(N, V, W, H, seed=0)
     my_views = views_of_rank(V, rank, world)
-    chunk = max(1, min(a.chunk if a.chunk != 32 else 64, len(my_views)))
+    chunk = max(1, min(a.chunk if a.chunk != 32 else 1000, len(my_views)))     # default: the rank's views in one call (6.1 GB of images)
     pool = chunk
     occ = torch.from_numpy(s.occ).to(dev)
     gen = torch.Generator(device=dev); gen.manual_seed(0)
