@@ -556,3 +556,25 @@ def test_reference_colour_script_chain_on_files(tmp_path, oracle_mod):
     assert len(zyx) > 100 and np.array_equal(d["image"], img)
     assert np.array_equal(got["projected_indices"].numpy(), zyx) and np.array_equal(got["pixel_indices"].numpy(), uv)
     assert got["projected_colors"].numpy().tobytes() == col.tobytes()
+
+
+def test_feature_feeder_delivers_every_map_in_order(tmp_path):
+    # the entry point's read-ahead (worker threads, pinned staging, copy stream) must hand over exactly the files' bytes, in
+    # file order, whatever the depth -- including more workers than files and maps of different shapes and dtypes
+    from aggregate_voxel_features_onthefly import FeatureFeeder
+    rng = np.random.default_rng(17)
+    paths, arrays = [], []
+    for i in range(7):
+        shape = (6, 5 + (i % 3), 9) if i != 4 else (3, 4, 4)
+        a = rng.standard_normal(shape).astype(np.float16 if i % 2 == 0 else np.float32)
+        p = tmp_path / f"m{i:02d}.npy"
+        np.save(p, a)
+        paths.append(str(p)); arrays.append(a)
+    for depth in (0, 1, 3, 16):
+        seen = []
+        for i, p, t in FeatureFeeder(paths, DEV, depth):
+            assert p == paths[i] and t.is_cuda
+            seen.append(t.cpu().numpy())
+        assert len(seen) == 7
+        for a, b in zip(arrays, seen):
+            assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
