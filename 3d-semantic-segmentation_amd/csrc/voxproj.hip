@@ -9,7 +9,7 @@
 //                          contraction, IEEE divide/sqrt, t += inc) -> first-hit voxel ID image and a
 //                          per-call integer hit histogram.  Pixel -> voxel assignment is bit-exact.
 //   phase 2  k_gather      one 64-lane wavefront per voxel: project the voxel's cube into every
-//                          view (lane = view, world->camera table from k_viewtab), scan the small pixel box in the ID
+//                          view (lane = view, world->camera table from k_worklist's trailing workgroups), scan the small pixel box in the ID
 //                          image for pixels that first-hit THIS voxel ("occlusion test"), and stream
 //                          their C-wide feature rows from HBM with 16-byte-per-lane coalesced loads,
 //                          accumulating in registers in (view, y, x) order; one non-atomic
@@ -261,13 +261,12 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
             if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
             hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
-        // the gather's work list: touched voxels by size class, largest first (needs the finished histogram)
-        hipLaunchKernelGGL(k_worklist, dim3((unsigned)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD))), dim3(256), 0, s1, (const int *)cnt_call, heavy_t,
-                           (long long)n_rows, work, status + ST_WORK0);
-        // the view table is phase 2's: computed behind the march, not in front of it (in pipelined mode a kernel with
-        // this many registers waits for a wavefront of the previous call's gather to retire; measured either way: no
-        // difference in the step time, so it sits where it cannot hold the march back)
-        hipLaunchKernelGGL(k_viewtab, dim3((B * V + 63) / 64), dim3(64), 0, s1, vmi, viewtab, B * V);
+        // the gather's work list: touched voxels by size class, largest first (needs the finished histogram); its trailing
+        // workgroups compute the view table, which is phase 2's too -- behind the march, not in front of it (in pipelined
+        // mode a kernel with that many registers waits for a wavefront of the previous call's gather to retire)
+        const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
+        hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, s1, (const int *)cnt_call, heavy_t,
+                           (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V);
         sp.end();
     }
     if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));

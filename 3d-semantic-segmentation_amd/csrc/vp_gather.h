@@ -513,8 +513,16 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
 constexpr int WL_PER_THREAD = 16;   // IDs per lane of k_worklist: a 256-thread workgroup bins 4096 voxel IDs
 
 __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, long long n_rows,
-                                                  int *__restrict__ work, int *work_n)
+                                                  int *__restrict__ work, int *work_n, int wl_blocks,
+                                                  const float *__restrict__ vmi, ViewEntry *viewtab, int n_views)
 {
+    if ((int)blockIdx.x >= wl_blocks) {
+        // trailing workgroups: the call's view table (phase 2's world->camera maps), one thread per view -- riding on
+        // this launch saves one kernel launch per call
+        const int v = ((int)blockIdx.x - wl_blocks) * 256 + (int)threadIdx.x;
+        if (v < n_views) view_entry(vmi, viewtab, v);
+        return;
+    }
     // Appends are aggregated per WORKGROUP through LDS: a handful of global atomics per 4096 IDs.  (Returning integer
     // atomics on a few hot addresses are exactly what slows a concurrently running gather -- DESIGN.md section 2.)
     __shared__ int n_cls[WORK_CLASSES], base_cls[WORK_CLASSES];

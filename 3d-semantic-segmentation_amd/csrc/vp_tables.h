@@ -157,12 +157,11 @@ __global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_viewtab: invert each view's 3x3 (double precision) for the phase-2 search boxes
+// view table: invert each view's 3x3 (double precision) for the phase-2 search boxes (computed by the trailing
+// workgroups of k_worklist, vp_gather.h)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_viewtab(const float *__restrict__ vmi, ViewEntry *tab, int n)
+__device__ __forceinline__ void view_entry(const float *__restrict__ vmi, ViewEntry *tab, int i)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const float *m = vmi + (long long)i * 16;
     double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], k = m[10];
     double A = e * k - f * h, Bc = -(d * k - f * g), Cc = d * h - e * g;
