@@ -100,3 +100,13 @@ def test_bench_entry_point_leg(mode):
     e = d["entry"]
     assert e["mode"] == mode and e["ms_per_view"] > 0 and e["dropin_ms_per_view"] > 0 and e["rows_out"] > 1000
     assert "R1 through the entry point" in d["config"]["workload"]
+
+
+def test_bench_contiguous_allocation_option():
+    # --alloc contiguous: resident buffers from hipExtMallocWithFlags(hipDeviceMallocContiguous), reported in the line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "S0", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--alloc", "contiguous"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert set(d["pool_placement"]["allocation"].values()) <= {"contiguous", "default"}
+    assert d["pool_placement"]["allocation"]["feature_pool"] == "contiguous" and d["value"] > 0
