@@ -121,7 +121,7 @@ class VoxelFeatureAggregator:
                 grown[:self._nonfinite.numel()] = self._nonfinite
                 self._nonfinite = grown
             # plain asynchronous calls (with one view per call the kernels are short: the extra stream and event traffic of
-            # the pipelined job mode costs more than the overlap returns, measured 0.30 vs 0.26 ms/view), through a call
+            # the pipelined job mode costs more than the overlap returns, measured 0.23 vs 0.20 ms/view), through a call
             # object that binds everything constant once -- the host side of a view is two foreign calls
             key = (H, W, tuple(float(v) for v in intr4.reshape(-1).tolist()), torch.cuda.current_stream(self.dev).cuda_stream)
             if getattr(self, "_prep_key", None) != key:
