@@ -175,7 +175,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("project_features_cuda", &project_features_cuda, "Projecting from 2D to 3D (MI355X / HIP)",
           py::arg("encoded_2d_features"), py::arg("occupancy_3D"), py::arg("viewMatrixInv"), py::arg("intrinsicParams"),
           py::arg("opts"), py::arg("mapping2dto3d_num"), py::arg("projected_features"), py::arg("pred_mode_t"),
-          py::arg("grid_origin"), py::arg("voxel_size"));
+          py::arg("grid_origin"), py::arg("voxel_size"),
+          // the call blocks until the device is done (like the reference, kernel.cu:454-457) but, unlike it, without
+          // holding the GIL: other Python threads -- a feature loader, say -- keep running meanwhile
+          py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return vp_abi_version(); });
     m.def("last_call", &last_call, "workspace address and shape of the last call on a device (test hook)");
 }
