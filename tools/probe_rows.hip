@@ -1,0 +1,58 @@
+// probe_rows.hip -- diagnostic only (tools/probe_levels.py): random whole-row gather into registers, the access shape of
+// k_gather without the projector, restricted to a WINDOW of the buffer.  Not part of libvoxproj.so.
+//
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/libprobe_rows.so tools/probe_rows.hip
+//
+// Every wavefront reads `iters` rows of `row_bytes` (1024 or 2048) picked by a hash of (wave, iteration) from the rows
+// [first_row, first_row + window_rows) of `src`, 16 B per lane per load, non-temporal, 4 rows in flight -- what a gather
+// wavefront does between two output rows.  Sweeping the window from 1 GB to the whole pool separates "how many distinct
+// pages are live at once" from everything else that distinguishes one allocation from the next.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace {
+
+__device__ __forceinline__ unsigned long long mix(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+template <int LOADS>   // 1-KiB wave-loads per row
+__global__ __launch_bounds__(256) void k_probe_rows(const float *__restrict__ src, long long first_row, long long window_rows,
+                                                    int iters, unsigned long long seed, float *sink)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    for (int it = 0; it < iters; it += U) {
+        v4f r[U][LOADS];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const unsigned long long h = mix(seed + wave * 0x9E3779B97F4A7C15ull + (unsigned long long)(it + j));
+            const long long row = first_row + (long long)(h % (unsigned long long)window_rows);
+            const float *p = src + row * (LOADS * 256) + lane * 4;
+#pragma unroll
+            for (int k = 0; k < LOADS; k++) r[j][k] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p + k * 256));
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++)
+#pragma unroll
+            for (int k = 0; k < LOADS; k++) acc += r[j][k];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;   // keeps the loads alive
+}
+
+}  // namespace
+
+extern "C" int probe_rows(const float *src, long long first_row, long long window_rows, int row_bytes, int waves, int iters,
+                          unsigned long long seed, float *sink, void *stream)
+{
+    if (!src || !sink || window_rows <= 0 || waves <= 0 || iters <= 0 || (row_bytes != 1024 && row_bytes != 2048)) return 1;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (row_bytes == 2048) hipLaunchKernelGGL(k_probe_rows<2>, grid, dim3(256), 0, (hipStream_t)stream, src, first_row, window_rows, iters, seed, sink);
+    else hipLaunchKernelGGL(k_probe_rows<1>, grid, dim3(256), 0, (hipStream_t)stream, src, first_row, window_rows, iters, seed, sink);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
