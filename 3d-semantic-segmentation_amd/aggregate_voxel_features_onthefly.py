@@ -52,9 +52,12 @@ _NEVER = 2 ** 30
 class VoxelFeatureAggregator:
     """Running per-voxel aggregate over views, resident on one GPU."""
 
-    def __init__(self, occ_zyx, grid_origin, voxel_size, channels, mode="parity", device="cuda"):
+    def __init__(self, occ_zyx, grid_origin, voxel_size, channels, mode="parity", device="cuda", parity_pipeline=False):
         self.dev = torch.device(device)
         self.mode = mode
+        self.parity_pipeline = bool(parity_pipeline)     # A/B: VP_FLAG_PIPELINE for the one-view calls of the parity mode
+        self._intr_dev = {}                              # intrinsics already on the device, by value
+        self._copy_stream = None
         self.occ3 = occ_zyx.to(self.dev).contiguous()
         self.occ = self.occ3.unsqueeze(0).long().contiguous()            # DPF:143
         self.grid_origin = [float(v) for v in grid_origin]
@@ -96,15 +99,38 @@ class VoxelFeatureAggregator:
     def _opts(self, W, H):
         return [float(W), float(H), 0.01, 10.0, float(np.float32(self.voxel_size * 0.5))]   # DPF:167-169
 
+    def _to_device_ready(self, t):
+        """A small host tensor (poses, intrinsics) as a float32 device tensor that is READY -- for the caller's stream
+        and for the library's side stream, which does not wait for the caller's (VP_FLAG_PIPELINE contract) -- without
+        waiting for the projector: pinned staging, a copy stream of its own, and a host wait on that copy alone.  (A plain
+        ``.to(device)`` from pageable memory synchronises torch's current stream, i.e. waits for the previous call's gather:
+        ADVICE r2.)  A tensor that is already on the device is the caller's promise that it is ready."""
+        if t.is_cuda:
+            return t.to(self.dev, torch.float32).contiguous()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(self.dev)
+        host = torch.empty(t.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(t)
+        with torch.cuda.stream(self._copy_stream):
+            d = host.to(self.dev, non_blocking=True)
+        self._copy_stream.synchronize()                  # the copy stream carries nothing else
+        return d
+
     def add_views(self, feats, c2w, intr4):
-        """feats f32 [V,H,W,C] on the GPU, c2w f32 [V,4,4], intr4 f32 [4] (shared by the call's views)."""
+        """feats f32 [V,H,W,C] on the GPU, c2w f32 [V,4,4], intr4 f32 [4] (shared by the call's views).  Host tensors are
+        staged without blocking on the projector; device tensors must be ready (not pending on a stream)."""
         V, H, W, C = feats.shape
         assert C == self.C
         if self.dev.type != "cuda":
             raise RuntimeError("VoxelFeatureAggregator.add_views projects on the GPU: there is no CPU path")
         feats = feats.contiguous()
-        intr = intr4.reshape(1, 4).to(self.dev, torch.float32).contiguous()
-        c2w = c2w.to(self.dev, torch.float32).contiguous()
+        ikey = tuple(float(v) for v in intr4.reshape(-1).tolist()) if not intr4.is_cuda else None
+        intr = self._intr_dev.get(ikey) if ikey is not None else None
+        if intr is None:
+            intr = self._to_device_ready(intr4.reshape(1, 4))
+            if ikey is not None:
+                self._intr_dev[ikey] = intr              # uploaded once per distinct intrinsics
+        c2w = self._to_device_ready(c2w)
         if self.mode == "parity":
             # One projector call per view (DPF runs once per image), then ONE hand-written epilogue over the rows that
             # view hit (vp_aggregate_view_f16): fp32 pixel sums -> fp16 (DPF:252) -> first-time clone / fp16 "+="
@@ -123,13 +149,14 @@ class VoxelFeatureAggregator:
             # plain asynchronous calls (with one view per call the kernels are short: the extra stream and event traffic of
             # the pipelined job mode costs more than the overlap returns, measured 0.23 vs 0.20 ms/view), through a call
             # object that binds everything constant once -- the host side of a view is two foreign calls
-            key = (H, W, tuple(float(v) for v in intr4.reshape(-1).tolist()), torch.cuda.current_stream(self.dev).cuda_stream)
+            key = (H, W, ikey if ikey is not None else intr.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
             if getattr(self, "_prep_key", None) != key:
                 self.flush()
                 self._prep_intr = intr
                 self._prep = voxproj_host.PreparedViewCalls(self.occ, intr, self._opts(W, H), self._cnt, self._sum,
                                                             self.grid_origin, self.voxel_size, self.ws, (1, 1, H, W, C),
-                                                            flags=voxproj_host.VP_FLAG_SERIAL_SUMS)   # the reference's bits
+                                                            flags=voxproj_host.VP_FLAG_SERIAL_SUMS |   # the reference's bits
+                                                            (voxproj_host.VP_FLAG_PIPELINE if self.parity_pipeline else 0))
                 self._prep_key = key
             for v in range(V):
                 self._prep(feats[v], vmis[v])

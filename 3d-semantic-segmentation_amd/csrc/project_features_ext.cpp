@@ -11,7 +11,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
-#include <cstdlib>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <optional>
@@ -35,9 +35,15 @@ struct DeviceState {
     std::vector<int64_t> occ_shape;
     int64_t n_rows = 0;
     std::vector<int64_t> last_call;                                   // B,V,H,W,C,dimz,dimy,dimx,n_rows (test hook)
+    uint64_t options_version = 0;                                     // g_options as last pushed to this device's workspace
 };
 std::mutex g_mu;
 std::map<int, DeviceState> g_state;
+// test / A-B switches (module functions set_exact_march / set_accel_cache; no environment variable is read)
+std::atomic<bool> g_exact_march{false};   // VP_FLAG_EXACT_MARCH: evaluate every ray sample like kernel.cu:47-82
+std::atomic<bool> g_accel_cache{true};    // keep the occupancy-derived tables between calls on an unchanged grid
+std::map<int, long long> g_options;       // vp_workspace_set_option values for this module's workspaces (set_workspace_option)
+uint64_t g_options_version = 1;           // both guarded by g_mu
 
 void *aligned_ptr(const at::Tensor &buf)
 {
@@ -116,9 +122,20 @@ void project_features_cuda(at::Tensor encoded_2d_features, at::Tensor occupancy_
         if (st.buf.defined()) vp_workspace_release(aligned_ptr(st.buf));
         st.buf = at::empty({(int64_t)need + 256}, at::TensorOptions().dtype(at::kByte).device(dev));
         st.occ.reset();
+        st.options_version = 0;
+        void *fresh = aligned_ptr(st.buf);
+        const int rc_ = vp_workspace_create(fresh, (size_t)st.buf.numel() - (size_t)((char *)fresh - (char *)st.buf.data_ptr()));
+        TORCH_CHECK(rc_ == VP_OK, "voxproj error ", rc_, ": ", vp_last_error());
     }
     void *ws = aligned_ptr(st.buf);
     const size_t capacity = (size_t)st.buf.numel() - (size_t)((char *)ws - (char *)st.buf.data_ptr());
+    if (st.options_version != g_options_version) {
+        for (const auto &kv : g_options) {
+            const int rc_ = vp_workspace_set_option(ws, kv.first, kv.second);
+            TORCH_CHECK(rc_ == VP_OK, "voxproj error ", rc_, ": ", vp_last_error());
+        }
+        st.options_version = g_options_version;
+    }
 
     // The occupancy-derived tables are reused only when this is the very same, still living tensor as in the
     // previous call with an unchanged version counter (an address match alone is not enough: the caching
@@ -126,16 +143,15 @@ void project_features_cuda(at::Tensor encoded_2d_features, at::Tensor occupancy_
     c10::TensorImpl *impl = occupancy_3D.unsafeGetTensorImpl();
     const bool tracked = !occupancy_3D.is_inference();
     const uint32_t version = tracked ? impl->version_counter().current_version() : 0;
-    const auto env_on = [](const char *name) { const char *e = std::getenv(name); return e && e[0] == '1' && !e[1]; };
+    const bool cache = g_accel_cache.load();
     const bool reuse = tracked && st.occ && !st.occ->expired() && st.occ->_unsafe_get_target() == impl &&
                        st.occ_version == version && st.occ_ptr == occupancy_3D.data_ptr() &&
-                       st.occ_shape == occupancy_3D.sizes().vec() && st.n_rows == n_rows &&
-                       !env_on("VOXPROJ_NO_ACCEL_CACHE");
+                       st.occ_shape == occupancy_3D.sizes().vec() && st.n_rows == n_rows && cache;
     // A/B arm of the leaping march: evaluate every ray sample (same results)
     // not the same tensor: let the library compare the grid with the copy its tables were built from (the reference's
     // caller makes a new, equal `.long()` tensor for every call, debug_project_features.py:143)
-    const int flags = VP_FLAG_SYNC | (reuse ? VP_FLAG_REUSE_ACCEL : (env_on("VOXPROJ_NO_ACCEL_CACHE") ? 0 : VP_FLAG_VERIFY_ACCEL)) |
-                      (env_on("VOXPROJ_EXACT_MARCH") ? VP_FLAG_EXACT_MARCH : 0);
+    const int flags = VP_FLAG_SYNC | (reuse ? VP_FLAG_REUSE_ACCEL : (cache ? VP_FLAG_VERIFY_ACCEL : 0)) |
+                      (g_exact_march.load() ? VP_FLAG_EXACT_MARCH : 0);
 
     // blocks until the device is done, GIL held, like the reference (kernel.cu:454-457)
     const int rc = vp_project_features(encoded_2d_features.data_ptr<float>(), occupancy_3D.data_ptr<int64_t>(),
@@ -180,5 +196,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           // holding the GIL: other Python threads -- a feature loader, say -- keep running meanwhile
           py::call_guard<py::gil_scoped_release>());
     m.def("abi_version", []() { return vp_abi_version(); });
+    m.def("set_exact_march", [](bool on) { g_exact_march.store(on); },
+          "A/B switch: evaluate every ray sample like the reference loop instead of leaping (same results, slower)");
+    m.def("set_workspace_option", [](int option, long long value) {
+              std::lock_guard<std::mutex> lock(g_mu);
+              g_options[option] = value;
+              g_options_version++;
+          },
+          "vp_workspace_set_option for this module's scratch workspaces (VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2; "
+          "negative = default)");
+    m.def("set_accel_cache", [](bool on) { g_accel_cache.store(on); },
+          "keep the occupancy-derived tables between calls on an unchanged occupancy grid (default on)");
     m.def("last_call", &last_call, "workspace address and shape of the last call on a device (test hook)");
 }

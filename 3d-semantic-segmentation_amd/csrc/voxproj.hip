@@ -39,7 +39,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "voxproj.h"
@@ -130,14 +132,15 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // buffer set and streams: plain calls use set 0 on the caller's stream only; pipelined calls alternate sets
     // and run phase 1 on the side stream
     const bool pipe = (flags & VP_FLAG_PIPELINE) != 0;
-    PipeState *ps = pipe_state(workspace, pipe);
-    if (pipe && !ps) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
+    WsState *st = ws_state(workspace, true);
+    PipeState *ps = &st->pipe;
+    if (pipe && !pipe_open(*ps)) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
     int q = 0;
     hipStream_t s1 = s0;
     if (pipe) {
         q = (int)(ps->calls & 1);
         s1 = ps->side;
-    } else if (ps && (ps->used[0] || ps->used[1])) {
+    } else if (ps->ok && (ps->used[0] || ps->used[1])) {
         // a plain call after pipelined ones on this workspace: drain the side streams first
         VP_HIP(hipStreamSynchronize(ps->side));
         ps->used[0] = ps->used[1] = false;
@@ -153,14 +156,16 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     int *work = (int *)(ws + l.work[q]);
     ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab[q]);
     int *hit = (int *)(ws + l.hit[q]);
-    remember_hit(workspace, l.hit[q]);
+    int *status0 = (int *)(ws + l.status[0]);      // header + sticky words live in the block of set 0
+    st->has_hit = true;
+    st->hit_off = l.hit[q];
 
     // Occupancy-derived tables: rebuilt unless the caller vouches for them (VP_FLAG_REUSE_ACCEL) or asks for a
     // check (VP_FLAG_VERIFY_ACCEL, blocking calls only): then the grid is compared with the copy the tables were
     // built from, and they are rebuilt only if a cell changed.
     const long long cells = (long long)dimz * dimy * dimx;
     int *occ_copy = (int *)(ws + l.occ_copy);
-    AccelRecord rec = accel_get(workspace);
+    WsState &rec = *st;
     const bool rec_matches = rec.B == B && rec.dimz == dimz && rec.dimy == dimy && rec.dimx == dimx && rec.n_rows == n_rows;
     const bool verify = (flags & VP_FLAG_VERIFY_ACCEL) && !pipe && !(flags & VP_FLAG_REUSE_ACCEL);
     const int cmp_blocks = (int)((cells * B + 255) / 256 > 8192 ? 8192 : (cells * B + 255) / 256);
@@ -171,12 +176,15 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (!rebuild && (rec.builds == 0 || !rec_matches))
         return fail(VP_EINVAL, "VP_FLAG_REUSE_ACCEL, but this workspace holds no occupancy tables for a grid of this shape "
                                "(B, dims, n_rows): call once without the flag");
-    if (!rec.status_init) {
-        // first call on this workspace memory: the sticky error words must start from zero
-        VP_HIP(hipMemsetAsync(ws + l.status[0], 0, l.status[1] - l.status[0] + ST_WORDS * sizeof(int), s0));
-        VP_HIP(hipStreamSynchronize(s0));
-        rec.status_init = true;
-        accel_put(workspace, rec);
+    if (rebuild || !rec.opened) {
+        // The workspace header (magic, this record's generation) and the sticky error words: initialised by the first call
+        // of a record and whenever the memory does not carry this record's generation (any more) -- decided on the
+        // device, no read-back.  A call that trusts the tables never initialises: it must find the header intact.
+        if (pipe && ps->ok) {
+            VP_HIP(hipStreamSynchronize(ps->side));
+        }
+        hipLaunchKernelGGL(k_ws_open, dim3(1), dim3(64), 0, s0, status0, (int *)(ws + l.status[1]), WS_MAGIC, rec.gen, rebuild ? 1 : 0);
+        rec.opened = true;
     }
     if (verify && rec_matches && rec.copy_valid) {
         int differs = 1;
@@ -198,7 +206,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // the tables are shared by both buffer sets: nothing of an earlier call may still be running
         if (pipe) {
             VP_HIP(hipStreamSynchronize(ps->side));
-                VP_HIP(hipStreamSynchronize(s0));
+            VP_HIP(hipStreamSynchronize(s0));
         }
         ProfSpan sp; sp.begin(0, s0);
         VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(B) * n_rows * sizeof(int), s0));
@@ -213,12 +221,14 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         const long long near_waves = (long long)l.nbz * l.nby * l.nbx * B;
         hipLaunchKernelGGL(k_build_near, dim3((unsigned)((near_waves + 3) / 4)), dim3(256), 0, s0, mask64, (const unsigned char *)dist,
                            near2, dimz, dimy, dimx, l.nbz, l.nby, l.nbx, l.nblk, B);
-        sp.end();
-        if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
         rec.B = B; rec.dimz = dimz; rec.dimy = dimy; rec.dimx = dimx; rec.n_rows = n_rows;
         rec.builds++;
-        accel_put(workspace, rec);
+        // seal: the header now names the tables this memory holds
+        hipLaunchKernelGGL(k_ws_seal, dim3(1), dim3(1), 0, s0, status0, tables_key(B, dimz, dimy, dimx, n_rows, rec.builds));
+        sp.end();
+        if (pipe) VP_HIP(hipStreamSynchronize(s0));   // rare: the side stream must see the finished tables
     }
+    const unsigned expect_tables = tables_key(rec.B, rec.dimz, rec.dimy, rec.dimx, rec.n_rows, rec.builds);
 
     if (pipe) {
         // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
@@ -227,13 +237,16 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
 
     // ---- phase 1 (on s1) ----
     int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
-    if (const char *e = getenv("VOXPROJ_HEAVY_T")) heavy_t = atoi(e) > 0 ? atoi(e) : heavy_t;
+    if (rec.opt_heavy_t > 0) heavy_t = (int)std::min<long long>(rec.opt_heavy_t, 2147483647ll);   // VP_OPT_HEAVY_THRESHOLD
     if (flags & VP_FLAG_SERIAL_SUMS) heavy_t = 2147483647;
-    if (getenv("VOXPROJ_DEBUG_EVALS")) heavy_t = -1;   // diagnostics only: the hit image then holds evaluation counts
+#ifdef VP_DIAG
+    if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
+#endif
     {
         ProfSpan sp; sp.begin(0, s1);
-        // one launch clears the per-call status words and the per-call histogram
-        hipLaunchKernelGGL(k_zero_call, dim3((unsigned)((n_rows + 1023) / 1024)), dim3(256), 0, s1, status, cnt_call, (long long)n_rows);
+        // one launch clears the per-call status words and the per-call histogram, and checks the workspace header
+        hipLaunchKernelGGL(k_zero_call, dim3((unsigned)((n_rows + 1023) / 1024)), dim3(256), 0, s1, status, cnt_call, (long long)n_rows,
+                           (const int *)status0, status0, WS_MAGIC, rec.gen, expect_tables);
         sp.end();
     }
     {
@@ -258,7 +271,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
                 (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
             }
             size_t lds_req = beside_gather ? 41 * 1024 : 0;
-            if (const char *e = getenv("VOXPROJ_FH_LDS_KB")) lds_req = size_t(atoi(e)) * 1024;
+            if (rec.opt_march_lds_kb >= 0) lds_req = size_t(std::min<long long>(rec.opt_march_lds_kb, 160)) * 1024;   // VP_OPT_MARCH_LDS_KB
             hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
         // the gather's work list: touched voxels by size class, largest first (needs the finished histogram); its trailing
@@ -302,7 +315,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         ps->used[q] = true;
         ps->last_q = q;
         ps->calls++;
-    } else if (ps) {
+    } else {
         ps->last_q = 0;
     }
     VP_HIP(hipGetLastError());
@@ -333,8 +346,8 @@ int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const flo
 
 static int read_status(void *workspace, hipStream_t stream, int *st /* [2][ST_WORDS] */)
 {
-    if (PipeState *ps = pipe_state(workspace, false)) {
-        VP_HIP(hipStreamSynchronize(ps->side));
+    if (WsState *rec = ws_state(workspace, false)) {
+        if (rec->pipe.ok) VP_HIP(hipStreamSynchronize(rec->pipe.side));
     }
     VP_HIP(hipMemcpyAsync(st, workspace, 2 * align256(ST_WORDS * sizeof(int)), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
@@ -371,13 +384,23 @@ int vp_workspace_status(void *workspace, void *stream_)
     int st[2 * ST_WORDS];
     int rc = read_status(workspace, (hipStream_t)stream_, st);
     if (rc != VP_OK) return rc;
-    if (!accel_get(workspace).status_init) return VP_OK;   // no call has run on this workspace yet
+    WsState *rec = ws_state(workspace, false);
+    if (!rec || !rec->opened) return VP_OK;   // no call has run on this workspace yet
     // the sticky words collect the errors of EVERY call since the last vp_workspace_status (the per-call words of a
-    // buffer set are cleared when the set is reused two pipelined calls later); reading them clears them
-    const int stuck = st[ST_STICKY_STUCK], badid = st[ST_STICKY_BADID];
-    if (stuck || badid) {
-        VP_HIP(hipMemsetAsync((int *)workspace + ST_STICKY_BADID, 0, 2 * sizeof(int), (hipStream_t)stream_));
+    // buffer set are cleared when the set is reused two pipelined calls later).  ONE condition is reported per read, and only
+    // the word that is reported is cleared: the others stay pending for the next read.
+    const int stale = st[ST_STICKY_STALE], stuck = st[ST_STICKY_STUCK], badid = st[ST_STICKY_BADID];
+    const int word = stale ? ST_STICKY_STALE : stuck ? ST_STICKY_STUCK : badid ? ST_STICKY_BADID : -1;
+    if (word >= 0) {
+        VP_HIP(hipMemsetAsync((int *)workspace + word, 0, sizeof(int), (hipStream_t)stream_));
         VP_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    }
+    if (stale) {
+        rec->builds = 0;        // whatever tables the memory held are gone: VP_FLAG_REUSE_ACCEL is refused until a rebuild
+        rec->copy_valid = false;
+        return fail(VP_EINVAL, "VP_FLAG_REUSE_ACCEL, but the workspace memory no longer holds the tables this library built in it "
+                               "(freed and handed out again without vp_workspace_release, or overwritten): those calls did no "
+                               "work; call once without the flag");
     }
     if (stuck)
         return fail(VP_EINVAL, "rayIncrement is too small to advance a float32 ray parameter near depthMax: the reference "
@@ -393,8 +416,8 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
     int st[2 * ST_WORDS];
     int rc = read_status(workspace, (hipStream_t)stream_, st);
     if (rc != VP_OK) return rc;
-    PipeState *ps = pipe_state(workspace, false);
-    const int q = ps ? ps->last_q : 0;
+    WsState *rec = ws_state(workspace, false);
+    const int q = rec ? rec->pipe.last_q : 0;
     memcpy(host_words, st + q * ST_WORDS, size_t(n) * sizeof(int));
     return VP_OK;
 }
@@ -428,11 +451,11 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
 {
     (void)C; (void)dimz; (void)dimy; (void)dimx; (void)n_rows;
     if (!workspace || !dst) return fail(VP_EINVAL, "null pointer argument");
-    size_t off = 0;
-    if (!recall_hit(workspace, off)) return fail(VP_EINVAL, "no vp_project_features call has used this workspace");
-    PipeState *ps = pipe_state(const_cast<void *>(workspace), false);
-    if (ps) {
-        VP_HIP(hipStreamSynchronize(ps->side));
+    WsState *rec = ws_state(workspace, false);
+    if (!rec || !rec->has_hit) return fail(VP_EINVAL, "no vp_project_features call has used this workspace");
+    const size_t off = rec->hit_off;
+    if (rec->pipe.ok) {
+        VP_HIP(hipStreamSynchronize(rec->pipe.side));
     }
     VP_HIP(hipMemcpyAsync(dst, (const char *)workspace + off, size_t(B) * V * H * W * sizeof(int),
                           hipMemcpyDeviceToDevice, (hipStream_t)stream_));
@@ -591,29 +614,34 @@ int vp_aggregate_view_f16(float *view_sum, int32_t *view_count, void *run16, int
 
 long long vp_workspace_table_builds(const void *workspace)
 {
-    return accel_get(workspace).builds;
+    WsState *rec = ws_state(workspace, false);
+    return rec ? rec->builds : 0;
+}
+
+int vp_workspace_create(void *workspace, size_t workspace_bytes)
+{
+    if (!workspace) return fail(VP_EINVAL, "null workspace");
+    if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
+    if (workspace_bytes < 2 * align256(ST_WORDS * sizeof(int))) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need at least %zu", workspace_bytes, 2 * align256(ST_WORDS * sizeof(int)));
+    ws_forget(workspace);            // whatever this address was before
+    (void)ws_state(workspace, true); // a new record, a new generation
+    return VP_OK;
+}
+
+int vp_workspace_set_option(void *workspace, int option, long long value)
+{
+    if (!workspace) return fail(VP_EINVAL, "null workspace");
+    WsState *rec = ws_state(workspace, true);
+    switch (option) {
+    case VP_OPT_HEAVY_THRESHOLD: rec->opt_heavy_t = value > 0 ? value : -1; return VP_OK;
+    case VP_OPT_MARCH_LDS_KB:    rec->opt_march_lds_kb = value >= 0 ? value : -1; return VP_OK;
+    default: return fail(VP_EINVAL, "unknown workspace option %d", option);
+    }
 }
 
 int vp_workspace_release(void *workspace)
 {
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (size_t i = 0; i < g_pipes.size(); i++)
-        if (g_pipes[i].first == workspace) {
-            PipeState *ps = g_pipes[i].second;
-            (void)hipStreamSynchronize(ps->side);
-            (void)hipStreamDestroy(ps->side);
-            for (int q = 0; q < 2; q++) {
-                (void)hipEventDestroy(ps->fh_done[q]);
-                (void)hipEventDestroy(ps->call_done[q]);
-            }
-            delete ps;
-            g_pipes.erase(g_pipes.begin() + i);
-            break;
-        }
-    for (size_t i = 0; i < g_last_hit.size(); i++)
-        if (g_last_hit[i].first == workspace) { g_last_hit.erase(g_last_hit.begin() + i); break; }
-    for (size_t i = 0; i < g_accel.size(); i++)
-        if (g_accel[i].first == workspace) { g_accel.erase(g_accel.begin() + i); break; }
+    ws_forget(workspace);
     return VP_OK;
 }
 

@@ -1,5 +1,5 @@
 // vp_common.h -- host-side plumbing shared by every part of libvoxproj: error text, HIP call checking, optional
-// per-kernel timing (HIP events), the per-workspace stream/event state of VP_FLAG_PIPELINE, kernel parameters and
+// per-kernel timing (HIP events), the per-workspace state record (streams/events of VP_FLAG_PIPELINE, table shape, options), kernel parameters and
 // the workspace layout.  Included by voxproj.hip only (one translation unit).
 #pragma once
 
@@ -68,11 +68,16 @@ struct ProfSpan {
 };
 
 // ------------------------------------------------------------------------------------------------
-// side stream + events for VP_FLAG_PIPELINE, one state per workspace pointer
+// Per-workspace state.  Everything the library remembers about a workspace lives in ONE record: the side stream and
+// events of VP_FLAG_PIPELINE, what the occupancy-derived tables in it were built for, the options set on it, where the
+// last call left its first-hit image.  The record is found through the workspace's address, but it is not trusted on
+// the address alone: every record has a GENERATION number that is also written into the workspace memory itself (the
+// header words of status block 0, below), together with a key of the tables' shape, and every call's first kernel
+// compares the two.  Memory that was freed without vp_workspace_release and handed out again -- or overwritten by
+// anyone -- no longer carries the generation the record expects: a call that trusts the tables (VP_FLAG_REUSE_ACCEL)
+// then does no work and raises the sticky ST_STICKY_STALE word (VP_EINVAL at the next status read), a call that
+// rebuilds them re-initialises the header and the sticky words first (k_ws_open).
 // ------------------------------------------------------------------------------------------------
-std::mutex g_pipe_mu;
-struct PipeState;
-std::vector<std::pair<void *, PipeState *>> g_pipes;
 struct PipeState {
     hipStream_t side = nullptr;    // phase 1
     hipEvent_t fh_done[2] = {nullptr, nullptr};      // phase 1 of buffer set q finished (side stream)
@@ -80,65 +85,80 @@ struct PipeState {
     bool used[2] = {false, false};
     long long calls = 0;
     int last_q = 0;
+    bool ok = false;
 };
-// Host-side record of the occupancy-derived tables held by a workspace: the shape they were built for, whether the
-// workspace also holds the 32-bit copy of the grid they were built from (VP_FLAG_VERIFY_ACCEL), and how often they
-// have been built (vp_workspace_table_builds).  Guarded by g_pipe_mu.
-struct AccelRecord {
+struct WsState {
+    unsigned gen = 0;                 // this record's generation (also in the workspace header once a call has run)
+    // occupancy-derived tables held by the workspace: the shape they were built for, whether the workspace also holds the
+    // 32-bit copy of the grid they were built from (VP_FLAG_VERIFY_ACCEL), how often they have been built
     int B = 0, dimz = 0, dimy = 0, dimx = 0;
     long long n_rows = 0;
     bool copy_valid = false;
     long long builds = 0;
-    bool status_init = false;   // the two status blocks have been zeroed once (sticky words start clean)
+    bool opened = false;              // k_ws_open has run for this record (header + sticky words initialised)
+    // options (vp_workspace_set_option); -1 = the library's default
+    long long opt_heavy_t = -1;
+    long long opt_march_lds_kb = -1;
+    // first-hit image of the last call (vp_copy_hit_image)
+    bool has_hit = false;
+    size_t hit_off = 0;
+    PipeState pipe;
 };
-std::vector<std::pair<const void *, AccelRecord>> g_accel;
-AccelRecord accel_get(const void *workspace)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_accel)
-        if (kv.first == workspace) return kv.second;
-    return AccelRecord();
-}
-void accel_put(const void *workspace, const AccelRecord &r)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_accel)
-        if (kv.first == workspace) { kv.second = r; return; }
-    g_accel.emplace_back(workspace, r);
-}
+std::mutex g_ws_mu;
+std::unordered_map<const void *, WsState *> g_ws;
+unsigned g_next_gen = 0;
 
-// offset of the first-hit image written by the last call on each workspace (vp_copy_hit_image)
-std::vector<std::pair<const void *, size_t>> g_last_hit;
-void remember_hit(const void *workspace, size_t off)
+// the record of a workspace (created on first use); records live until vp_workspace_release / vp_workspace_create
+WsState *ws_state(const void *workspace, bool create)
 {
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_last_hit)
-        if (kv.first == workspace) { kv.second = off; return; }
-    g_last_hit.emplace_back(workspace, off);
-}
-bool recall_hit(const void *workspace, size_t &off)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_last_hit)
-        if (kv.first == workspace) { off = kv.second; return true; }
-    return false;
-}
-
-PipeState *pipe_state(void *workspace, bool create)
-{
-    std::lock_guard<std::mutex> g(g_pipe_mu);
-    for (auto &kv : g_pipes)
-        if (kv.first == workspace) return kv.second;
+    std::lock_guard<std::mutex> g(g_ws_mu);
+    auto it = g_ws.find(workspace);
+    if (it != g_ws.end()) return it->second;
     if (!create) return nullptr;
-    PipeState *ps = new PipeState();
+    if (g_next_gen == 0) g_next_gen = (unsigned)std::chrono::steady_clock::now().time_since_epoch().count() | 1u;
+    WsState *st = new WsState();
+    st->gen = g_next_gen;
+    g_next_gen += 2;                  // stays odd: never 0
+    g_ws.emplace(workspace, st);
+    return st;
+}
+
+void pipe_destroy(PipeState &ps)
+{
+    if (!ps.ok) return;
+    (void)hipStreamSynchronize(ps.side);
+    (void)hipStreamDestroy(ps.side);
+    for (int q = 0; q < 2; q++) {
+        (void)hipEventDestroy(ps.fh_done[q]);
+        (void)hipEventDestroy(ps.call_done[q]);
+    }
+    ps = PipeState();
+}
+
+void ws_forget(const void *workspace)
+{
+    WsState *st = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_ws_mu);
+        auto it = g_ws.find(workspace);
+        if (it == g_ws.end()) return;
+        st = it->second;
+        g_ws.erase(it);
+    }
+    pipe_destroy(st->pipe);
+    delete st;
+}
+
+bool pipe_open(PipeState &ps)
+{
+    if (ps.ok) return true;
     // (a high-priority side stream was measured: no effect on the pipelined step time, so plain streams)
-    bool ok = hipStreamCreateWithFlags(&ps->side, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ps.side, hipStreamNonBlocking) == hipSuccess;
     for (int q = 0; q < 2 && ok; q++)
-        ok = hipEventCreateWithFlags(&ps->fh_done[q], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&ps->call_done[q], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { delete ps; return nullptr; }
-    g_pipes.emplace_back(workspace, ps);
-    return ps;
+        ok = hipEventCreateWithFlags(&ps.fh_done[q], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ps.call_done[q], hipEventDisableTiming) == hipSuccess;
+    ps.ok = ok;
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,10 +177,27 @@ struct Params {
 // on the set, read by vp_workspace_counters.  ST_STICKY_* live in the block of set 0 only, are raised together with
 // their per-call twins, survive every later call on the workspace and are cleared by vp_workspace_status alone --
 // so an error raised by pipelined call j is still there when the job finally asks, however many calls later.
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5,
+// ST_HDR_*: the workspace header (set 0 only): magic, the generation of the record that initialised this memory, the key
+// of the tables it holds (0 while none are sealed) -- written by k_ws_open / k_ws_seal, compared by every call's k_zero_call.
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_STUCK = 4, ST_OCCDIFF = 5, ST_STALE = 6,
        ST_WORK0 = 16, WORK_CLASSES = 8,        // per-call: number of voxels in each size class of the gather's work list
        ST_CALL_WORDS = 32,
-       ST_STICKY_BADID = 62, ST_STICKY_STUCK = 63, ST_WORDS = 64 };
+       ST_HDR_MAGIC = 56, ST_HDR_GEN = 57, ST_HDR_TABLES = 58,
+       ST_STICKY_STALE = 61, ST_STICKY_BADID = 62, ST_STICKY_STUCK = 63, ST_WORDS = 64 };
+constexpr unsigned WS_MAGIC = 0x56585033u;   // "VXP3"
+#ifdef VP_DIAG
+enum { VP_FLAG_DIAG_EVALS = 1 << 20 };      // diagnostic build only (make diag): the hit image receives per-ray evaluation counts
+#endif
+
+// key of the tables a workspace holds: shape they were built for + how many times this record has built them
+inline unsigned tables_key(int B, int dimz, int dimy, int dimx, long long n_rows, long long builds)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    const long long v[6] = {B, dimz, dimy, dimx, n_rows, builds};
+    for (long long x : v) { h ^= (unsigned long long)x + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xff51afd7ed558ccdull; }
+    const unsigned k = (unsigned)(h ^ (h >> 32));
+    return k ? k : 1u;     // 0 means "no tables"
+}
 
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {

@@ -551,6 +551,31 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
             work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
 }
 
+// Which entry of a size class the w-th wavefront of the class takes.  The list of a class is in ascending ID order, i.e. in
+// the order of the voxels' positions: taken as it stands, the few thousand wavefronts in flight at any moment gather from
+// the SAME few regions of the same views -- a structured set of addresses whose spread over the HBM channels depends on
+// where the driver placed the feature pool (two speed levels, 4.6 % apart alone and up to 12 % pipelined, following the
+// pool's allocation: profiles/r03_levels_*).  A multiplicative permutation of the class scatters the wavefronts in
+// flight over the whole scene; every voxel is still summed by one wavefront in (b,v,y,x) order, so results are unchanged.
+#ifndef VP_WORK_PERMUTE
+#define VP_WORK_PERMUTE 1
+#endif
+__device__ __forceinline__ unsigned class_slot(unsigned w, unsigned n)
+{
+#if VP_WORK_PERMUTE
+    // w -> (w * P) mod n is a bijection of [0, n) whenever gcd(P, n) = 1: P prime and n < P.  Of two primes the one whose
+    // residue (= the stride between consecutive wavefronts) is not within n/16 of 0 or n is taken.
+    if (n < 64u) return w;
+    unsigned long long P = 2654435761ull;
+    const unsigned r = (unsigned)(P % n);
+    if (r < n / 16u || n - r < n / 16u) P = 2246822519ull;
+    return (unsigned)(((unsigned long long)w * P) % n);
+#else
+    (void)n;
+    return w;
+#endif
+}
+
 // MERGED = true: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of 8 or more views); 97 VGPRs,
 // i.e. 4 wavefronts per SIMD -- in pipelined mode a gain, because a fifth gather wave would take the room the next call's
 // march needs (forcing <= 96 registers with __launch_bounds__(256, 5), one allocation: pipelined +2.5 % fp16 / +2 % R1 /
@@ -590,7 +615,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 #pragma unroll
     for (int k = WORK_CLASSES - 1; k >= 0; k--) {
         const int n = g.work_n[k];
-        if (id == 0 && w < n) id = g.work[(long long)k * p.n_rows + w];
+        if (id == 0 && w < n) id = g.work[(long long)k * p.n_rows + class_slot((unsigned)w, (unsigned)n)];
         w -= n;
     }
     if (id == 0) return;

@@ -57,6 +57,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     const int heavy_t = fa.heavy_t;
     const int b = bv / p.V;
     if (x >= p.width || y >= p.height) return;
+    if (status[ST_STALE]) return;      // the workspace does not hold the tables this call was told to trust (k_zero_call)
 
     const float *m = vmi + (long long)bv * 16;           // K.cu:178-179 (row-major float4x4)
     const float fx = intr[b * 4 + 0], fy = intr[b * 4 + 1], mx = intr[b * 4 + 2], my = intr[b * 4 + 3];
@@ -127,7 +128,9 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
         unsigned cur_blk = 0xffffffffu;
         int cur_d = 0;
         unsigned long long cur_lo = 0ull, cur_hi = 0ull;
+#ifdef VP_DIAG
         int dbg_leap = 0, dbg_fine = 0;
+#endif
         // binade cache of the closed-form t advance (derivation: "Closed-form advance" in vp_tables.h): valid while t < bT2
         float bT2 = 0.0f, bTu = 0.0f, bg = 0.0f, brg = 0.0f;
         while (t < tEnd) {
@@ -178,7 +181,9 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                 const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
                 D = max(dbox, din - dbox);
             }
+#ifdef VP_DIAG
             if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
+#endif
             // advance by 1 + J samples, J = floor((D - 1.5) / dcell) of them provably unable to reach an occupied
             // cell; the running sum t is reproduced exactly by the closed form, with the binade constants cached
             // across evaluations
@@ -204,10 +209,12 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                 if (S <= 0 || !(t < tEnd)) break;
             }
         }
-        if (heavy_t < 0) {   // diagnostic build path (VOXPROJ_DEBUG_EVALS): per-ray evaluation counts instead of IDs
+#ifdef VP_DIAG
+        if (heavy_t < 0) {   // diagnostic build only (make diag, VP_FLAG_DIAG_EVALS): per-ray evaluation counts instead of IDs
             hit[((long long)bv * p.height + y) * p.width + x] = (dbg_leap << 16) | dbg_fine;
             return;
         }
+#endif
     }
     if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
         atomicOr(&status[ST_BADID], 1);

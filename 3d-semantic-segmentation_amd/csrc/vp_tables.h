@@ -146,11 +146,42 @@ __global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__
     if (lane == 0) near2[(long long)b * nblk + blk] = make_ulonglong2(lo, hi);
 }
 
-// per-call reset: the status words of this buffer set and the per-call hit histogram, in one launch
-__global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int *__restrict__ cnt_call, long long n_rows)
+// Workspace header (vp_common.h, WsState): initialise the status blocks of memory that does not carry this record's
+// generation (first call of a record, or memory recycled / overwritten since), leave them alone otherwise -- so pending
+// sticky errors survive a table rebuild.  One workgroup of 64 threads, one status word each.
+__global__ __launch_bounds__(64) void k_ws_open(int *status0, int *status1, unsigned magic, unsigned gen, int may_init)
+{
+    const bool ok = (unsigned)status0[ST_HDR_MAGIC] == magic && (unsigned)status0[ST_HDR_GEN] == gen;
+    __syncthreads();
+    if (ok || !may_init) return;
+    const int t = threadIdx.x;
+    status0[t] = t == ST_HDR_MAGIC ? (int)magic : t == ST_HDR_GEN ? (int)gen : 0;     // ST_HDR_TABLES = 0: no tables yet
+    status1[t] = 0;
+}
+
+// after a table build: the header names the tables this memory now holds
+__global__ void k_ws_seal(int *status0, unsigned tables) { status0[ST_HDR_TABLES] = (int)tables; }
+
+// per-call reset: the status words of this buffer set and the per-call hit histogram, in one launch; one thread also
+// compares the workspace header with what the host record expects (generation, tables key).  A mismatch marks the call
+// stale: k_first_hit then does nothing (so neither does the gather: the histogram stays zero) and the sticky word makes
+// vp_workspace_status report it.
+__global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int *__restrict__ cnt_call, long long n_rows,
+                                                   const int *hdr, int *sticky, unsigned magic, unsigned gen, unsigned tables)
 {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (blockIdx.x == 0 && threadIdx.x < ST_CALL_WORDS) status[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < ST_CALL_WORDS) {
+        int v = 0;
+        if (threadIdx.x == ST_STALE) {
+            const bool mine = (unsigned)hdr[ST_HDR_MAGIC] == magic && (unsigned)hdr[ST_HDR_GEN] == gen;
+            if (!mine || (unsigned)hdr[ST_HDR_TABLES] != tables) {
+                v = 1;
+                if (!mine) { sticky[ST_STICKY_BADID] = 0; sticky[ST_STICKY_STUCK] = 0; }   // not this record's words: garbage
+                sticky[ST_STICKY_STALE] = 1;
+            }
+        }
+        status[threadIdx.x] = v;
+    }
     if (i + 3 < n_rows) *reinterpret_cast<int4 *>(cnt_call + i) = make_int4(0, 0, 0, 0);
     else
         for (long long j = i; j < n_rows; j++) cnt_call[j] = 0;

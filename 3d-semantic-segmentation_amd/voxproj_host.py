@@ -23,6 +23,25 @@ VP_FLAG_SERIAL_SUMS = 32
 _lib = None
 _lock = threading.Lock()
 
+# test / A-B switches of the ctypes front (module attributes, not environment variables; the compiled front has
+# project_features_cuda.set_exact_march / set_accel_cache)
+EXACT_MARCH = False      # evaluate every ray sample like K.cu:47-82 (VP_FLAG_EXACT_MARCH)
+ACCEL_CACHE = True       # keep the occupancy-derived tables between calls on the same, unmodified occupancy tensor
+_default_options = {}    # {VP_OPT_*: value} applied to every Workspace of this module (set_default_option)
+_options_version = 0
+
+
+def set_default_option(option, value):
+    """Default of a workspace option (VP_OPT_HEAVY_THRESHOLD, VP_OPT_MARCH_LDS_KB) for every Workspace object of this
+    process, existing ones included (they pick it up at their next call); None = the library's default.  A Workspace's
+    own set_option wins.  Test / A-B switch: production code leaves the defaults alone."""
+    global _options_version
+    if value is None:
+        _default_options.pop(int(option), None)
+    else:
+        _default_options[int(option)] = int(value)
+    _options_version += 1
+
 EXPORTS = [
     "vp_abi_version", "vp_last_error", "vp_workspace_bytes", "vp_project_features",
     "vp_workspace_status", "vp_workspace_counters", "vp_copy_hit_image",
@@ -30,8 +49,11 @@ EXPORTS = [
     "vp_project_features_f16", "vp_nearest_voxel",
     "vp_stream_read", "vp_workspace_table_builds", "vp_colors_workspace_bytes",
     "vp_upsample_workspace_bytes", "vp_upsample_features", "vp_voxel_coords", "vp_scatter_occupancy",
-    "vp_aggregate_view_f16",
+    "vp_aggregate_view_f16", "vp_workspace_create", "vp_workspace_set_option",
 ]
+VP_ABI_VERSION = 3
+VP_OPT_HEAVY_THRESHOLD = 1
+VP_OPT_MARCH_LDS_KB = 2
 
 
 class VoxprojError(RuntimeError):
@@ -108,6 +130,10 @@ def lib():
             L.vp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
             L.vp_workspace_release.restype = ctypes.c_int
             L.vp_workspace_release.argtypes = [vp]
+            L.vp_workspace_create.restype = ctypes.c_int
+            L.vp_workspace_create.argtypes = [vp, ctypes.c_size_t]
+            L.vp_workspace_set_option.restype = ctypes.c_int
+            L.vp_workspace_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
             L.vp_workspace_table_builds.restype = ctypes.c_longlong
             L.vp_workspace_table_builds.argtypes = [vp]
             L.vp_project_colors.restype = ctypes.c_int
@@ -130,6 +156,8 @@ def lib():
                                                ctypes.c_int, vp, vp, vp]
             L.vp_aggregate_view_f16.restype = ctypes.c_int
             L.vp_aggregate_view_f16.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int64, ctypes.c_int, vp]
+            if L.vp_abi_version() != VP_ABI_VERSION:
+                raise VoxprojError(f"{LIB_PATH} has ABI version {L.vp_abi_version()}, this package needs {VP_ABI_VERSION}: rebuild it")
             _lib = L
     return _lib
 
@@ -148,11 +176,15 @@ def workspace_bytes(B, V, H, W, C, dimz, dimy, dimx, n_rows):
 
 
 class Workspace:
-    """Grow-only device scratch buffer (one per device), allocated through torch's allocator."""
+    """Grow-only device scratch buffer (one per device), allocated through torch's allocator, announced to the library with
+    vp_workspace_create and withdrawn with vp_workspace_release.  ``options``: {VP_OPT_*: value}, applied to every buffer
+    this object ever holds (set_option)."""
 
     def __init__(self):
         self.buf = None
         self.accel_key = None     # (weakref to the occupancy tensor, its _version, shape, n_rows)
+        self.options = {}
+        self._applied = None      # (module options version, own options) last pushed to the library for self.buf
 
     def ensure(self, nbytes, device):
         import torch
@@ -164,7 +196,30 @@ class Workspace:
             self.release()
             self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
             self.accel_key = None
+            check(lib().vp_workspace_create(self.ptr(), self.capacity()))      # whatever this address was before is forgotten
+            self._applied = None
+        self._push_options()
         return self.ptr()
+
+    def _push_options(self):
+        state = (_options_version, tuple(sorted(self.options.items())))
+        if self.buf is None or self._applied == state:
+            return
+        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1}
+        merged.update(_default_options)
+        merged.update(self.options)
+        for opt, val in merged.items():
+            check(lib().vp_workspace_set_option(self.ptr(), int(opt), int(val)))
+        self._applied = state
+
+    def set_option(self, option, value):
+        """vp_workspace_set_option (VP_OPT_HEAVY_THRESHOLD, VP_OPT_MARCH_LDS_KB); None = fall back to the module default /
+        the library's.  Remembered, so it survives the buffer growing."""
+        if value is None:
+            self.options.pop(int(option), None)
+        else:
+            self.options[int(option)] = int(value)
+        self._push_options()
 
     def ptr(self):
         return (self.buf.data_ptr() + 255) & ~255
@@ -207,7 +262,7 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     alive) tensor object as in the previous call on this workspace, with an unchanged torch version
     counter -- a data_ptr match alone is not enough, the caching allocator hands freed addresses out
     again; True/False = force.  ``exact_march``: evaluate every ray sample (A/B arm of the leaping march;
-    default from env VOXPROJ_EXACT_MARCH).  ``pipeline``: asynchronous job mode (VP_FLAG_PIPELINE): phase 1 of
+    default: module attribute EXACT_MARCH).  ``pipeline``: asynchronous job mode (VP_FLAG_PIPELINE): phase 1 of
     this call overlaps the previous call's gather; the caller must keep occ/vmi/intr alive and unchanged
     until ``workspace_status`` (or a device synchronise) and must not pass sync.  ``views_hit``: optional
     int32 [n_rows] tensor, += number of views of this call that hit each voxel.  ``verify_accel``: when the tables
@@ -225,14 +280,12 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     key = (occ._version, occ.data_ptr(), tuple(occ.shape), n_rows)
     if reuse_accel is None:
         prev = ws.accel_key
-        reuse_accel = (prev is not None and prev[0]() is occ and prev[1] == key
-                       and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1")
+        reuse_accel = (prev is not None and prev[0]() is occ and prev[1] == key and ACCEL_CACHE)
     if exact_march is None:
-        exact_march = os.environ.get("VOXPROJ_EXACT_MARCH", "0") == "1"
+        exact_march = EXACT_MARCH
     flags = ((VP_FLAG_SYNC if (sync and not pipeline) else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
              | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0)
-             | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel
-                                         and os.environ.get("VOXPROJ_NO_ACCEL_CACHE", "0") != "1") else 0))
+             | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel and ACCEL_CACHE) else 0))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream
@@ -433,13 +486,18 @@ def aggregate_view_f16(view_sum, view_count, run16, views, first_view, view_inde
     Asynchronous on ``stream`` (a raw hipStream_t value; default: torch's current stream).  The tensors' checks and
     pointers are cached per argument set (the aggregator calls this once per view with the same tensors)."""
     import torch
-    key = (view_sum.data_ptr(), view_count.data_ptr(), run16.data_ptr(), views.data_ptr(), first_view.data_ptr(), nonfinite.data_ptr())
+    # the cache key holds the SHAPES as well as the addresses: the caching allocator hands freed addresses out again, and a
+    # second aggregator with fewer rows or channels can receive the very same six pointers
+    key = (view_sum.data_ptr(), view_count.data_ptr(), run16.data_ptr(), views.data_ptr(), first_view.data_ptr(), nonfinite.data_ptr(),
+           tuple(view_sum.shape), tuple(run16.shape), view_count.numel(), views.numel(), first_view.numel())
     c = _agg_cache.get("k")
     if c is None or c[0] != key:
         n_rows, C = (int(v) for v in view_sum.shape)
         assert view_sum.dtype == torch.float32 and view_sum.is_contiguous() and view_count.dtype == torch.int32
         assert run16.dtype == torch.float16 and run16.is_contiguous() and tuple(run16.shape) == (n_rows, C)
         assert views.dtype == torch.int32 and first_view.dtype == torch.int32 and nonfinite.dtype == torch.int32
+        assert view_count.numel() == n_rows and views.numel() == n_rows and first_view.numel() == n_rows
+        assert view_count.is_contiguous() and views.is_contiguous() and first_view.is_contiguous()
         c = _agg_cache["k"] = (key, n_rows, C, lib().vp_aggregate_view_f16, view_sum.device)
     _, n_rows, C, fn, dev = c
     if stream is None:

@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--entry", default=None, choices=("parity", "fast"),
                     help="time the named entry point's in-process aggregation (VoxelFeatureAggregator.add_views over every "
                          "view of the workload, features resident) instead of raw C-ABI calls; default workload R1")
+    ap.add_argument("--entry-pipeline", action="store_true",
+                    help="--entry parity: A/B arm, run the one-view calls in the pipelined job mode (VP_FLAG_PIPELINE)")
     ap.add_argument("--collective", default="reduce", choices=("reduce", "allreduce"),
                     help="multi-GPU: how the per-rank {sum,count} are combined each pass.  reduce (default) = to rank 0 only, "
                          "half the xGMI traffic, enough when one rank writes the scene; allreduce = every rank gets the scene")
@@ -80,6 +82,9 @@ def parse():
                          "hipDeviceMallocContiguous; falls back to the plain allocator if no such range is free) -- an experiment "
                          "on the placement spread, DESIGN.md section 4: it pins a 17 GB pool to one speed level inside a process, "
                          "but does not remove the spread between processes")
+    ap.add_argument("--heavy-threshold", type=int, default=0,
+                    help="experiment: VP_OPT_HEAVY_THRESHOLD of the workspace (pixels per voxel and call above which a whole "
+                         "workgroup sums the voxel); 0 = the library's default, 256 + 64 x views per call")
     ap.add_argument("--no-overlap-reduce", action="store_true",
                     help="multi-GPU: wait for each pass's all-reduce before starting the next pass (default: the "
                          "all-reduce of pass k runs on RCCL's stream while pass k+1 is projected into a second buffer)")
@@ -329,15 +334,20 @@ def bench_entry(a, dev, rank, world, dist):
     make_features_torch(pool, H, W, C, dev, seed=0, out=feats)
     c2w = torch.from_numpy(s.c2w).to(dev)
     intr4 = torch.from_numpy(s.intr)
-    agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, C, a.entry, dev)
+    agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, C, a.entry, dev,
+                                 parity_pipeline=a.entry_pipeline)
     per_call = 1 if a.entry == "parity" else max(1, min(8, a.chunk))
     calls = [my_views[i:i + per_call] for i in range(0, len(my_views), per_call)]
+    # the poses of every call, on the device and READY before the first call (a pipelined call's side stream reads them
+    # without waiting for the caller's stream: an index kernel still pending there would be a contract violation)
+    c2ws = [c2w[vs].contiguous() for vs in calls]
+    torch.cuda.synchronize(dev)
 
     def step():
         agg.reset()
-        for vs in calls:
+        for ci, vs in enumerate(calls):
             slot = vs[0] % pool if (vs[0] % pool) + len(vs) <= pool else 0
-            agg.add_views(feats[slot:slot + len(vs)], c2w[vs], intr4)
+            agg.add_views(feats[slot:slot + len(vs)], c2ws[ci], intr4)
         if dist is not None:
             agg.all_reduce(dst=0 if a.collective == "reduce" else None)
         else:
@@ -491,6 +501,8 @@ def main():
     opts = [float(v) for v in scene.opts()]
     origin = [float(v) for v in scene.grid_origin]
     ws = voxproj_host.Workspace()
+    if a.heavy_threshold > 0:
+        ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, a.heavy_threshold)
 
     # calls of one step: (pool slot of the first view, view indices)
     calls = []
@@ -584,7 +596,7 @@ def main():
         touched += nt
         # voxels above the library's per-call threshold (256 + 64*B*V pixels) are summed by the leading workgroups of
         # the same k_gather launch: every hit pixel's row and every touched output row count for this kernel
-        heavy = count > (int(os.environ.get("VOXPROJ_HEAVY_T", "0")) or (256 + 64 * len(calls[ci][1])))
+        heavy = count > (a.heavy_threshold or (256 + 64 * len(calls[ci][1])))
         heavy_px += int(count[heavy].sum().item())
         gather_bytes += ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
         c1 = voxproj_host.counters(ws, dev)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 2
+#define VP_ABI_VERSION 3
 
 enum {
     VP_OK = 0,
@@ -152,9 +152,11 @@ int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const flo
                             void *stream, int flags);
 
 /*
- * Drains the workspace's streams, then reads back AND CLEARS the sticky device-side error words of the workspace:
- * they collect the errors (out-of-range ID: VP_EBADID; a ray parameter that cannot advance: VP_EINVAL) of EVERY call
- * made on the workspace since the previous vp_workspace_status, pipelined or not -- no later call erases them.
+ * Drains the workspace's streams, then reads back the sticky device-side error words of the workspace: they collect the
+ * errors (tables gone from recycled memory: VP_EINVAL; a ray parameter that cannot advance: VP_EINVAL; out-of-range ID:
+ * VP_EBADID) of EVERY call made on the workspace since they were last reported, pipelined or not -- no later call erases
+ * them.  One condition is reported per call, in that order, and only the reported one is cleared: call again (until
+ * VP_OK) to see the others.
  * The reference only prints device errors (K.cu:454-457, cutilCheckMsg); here they surface as a return code.
  * Returns VP_OK when no call has reported anything.
  */
@@ -252,10 +254,32 @@ int vp_aggregate_view_f16(float *view_sum, int32_t *view_count, void *run16, int
                           int view_index, int32_t *nonfinite_dev, int64_t n_rows, int C, void *stream);
 
 /*
- * Forgets the side streams / events the library keeps for a workspace that was used with
- * VP_FLAG_PIPELINE (drains them first); call before freeing or recycling the workspace memory.
+ * Workspace lifetime.  The library keeps ONE record per workspace (side stream and events of VP_FLAG_PIPELINE, the shape
+ * the occupancy tables in it were built for, its options).  The record is looked up by the workspace's address but is
+ * not trusted on the address alone: its generation number is also written into the workspace memory (a header in the
+ * first 256 bytes) and compared, on the device, by every call -- so memory that was freed and handed out again, or
+ * overwritten, is recognised: calls that trust the tables (VP_FLAG_REUSE_ACCEL) then do no work and the next
+ * vp_workspace_status returns VP_EINVAL; calls that rebuild them re-initialise the header.
+ *
+ *   vp_workspace_create   "this memory is a new workspace": drops any record the address had (streams, tables, options)
+ *                         and starts a new generation.  Optional for memory the library has never seen (the first call
+ *                         creates the record), REQUIRED manners for memory that is being reused as a workspace.
+ *   vp_workspace_release  drains and destroys the record; call before freeing or recycling the memory.
+ * No reference counterpart (the reference allocates nothing between calls).
  */
+int vp_workspace_create(void *workspace, size_t workspace_bytes);
 int vp_workspace_release(void *workspace);
+
+/*
+ * Options of a workspace, read by the calls made on it (they replace the environment variables of ABI v2; the
+ * library reads no environment variable).  value < 0 (or 0 for the threshold) restores the default.
+ *   VP_OPT_HEAVY_THRESHOLD  voxels that collect more than this many pixels in ONE call are summed by a whole workgroup
+ *                           (default 256 + 64*B*V; VP_FLAG_SERIAL_SUMS overrides it with "never")
+ *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default: 41 KiB
+ *                           beside a running gather in VP_FLAG_PIPELINE mode, 0 otherwise)
+ */
+enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2 };
+int vp_workspace_set_option(void *workspace, int option, long long value);
 
 /* How many times the occupancy-derived tables of this workspace have been (re)built so far (0 if never);
  * diagnostic for VP_FLAG_REUSE_ACCEL / VP_FLAG_VERIFY_ACCEL. */

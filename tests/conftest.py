@@ -19,3 +19,21 @@ def oracle_mod():
     from oracle import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture
+def heavy_threshold():
+    """Setter for VP_OPT_HEAVY_THRESHOLD on every workspace of both fronts (None = the library's default, 256 + 64*B*V);
+    the default is restored afterwards.  Replaces the environment variable of ABI v2: options belong to the workspace."""
+    import voxproj_host
+
+    def set_(value):
+        voxproj_host.set_default_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, value)
+        try:
+            import torch  # noqa: F401
+            import project_features_cuda as m
+            m.set_workspace_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, -1 if value is None else int(value))
+        except ImportError:
+            pass
+    yield set_
+    set_(None)

@@ -1,5 +1,5 @@
 """GPU parity at the BASELINE.json configurations' OWN shapes, with the library's production settings
-(no VOXPROJ_HEAVY_T override: voxels above 256 + 64*B*V pixels per call take the workgroup path).
+(no heavy-threshold override: voxels above 256 + 64*B*V pixels per call take the workgroup path).
 
   config 2  R1  ~80k voxels, 484x274x512 feature maps          -> 4 views in one call vs the oracle
   config 3  R2  200k voxels, 968x548x512 feature maps          -> 8 views in ONE call vs the oracle

@@ -14,10 +14,10 @@ DEV = "cuda:0"
 
 
 @pytest.fixture(autouse=True)
-def _no_heavy_path_by_default(monkeypatch):
+def _no_heavy_path_by_default(heavy_threshold):
     # the bit-identical-sums assertions hold for voxels summed by ONE wavefront; keep the workgroup path
     # (different, fixed summation tree) out of those tests.  test_heavy_voxels_* lowers it again.
-    monkeypatch.setenv("VOXPROJ_HEAVY_T", "100000000")
+    heavy_threshold(100000000)
 
 
 FRONT = {"name": "compiled"}
@@ -202,12 +202,12 @@ def test_id_labelling_several_cells_falls_back_to_full_scan(oracle_mod):
              expect_boxmiss=True)
 
 
-def test_heavy_voxels_use_the_workgroup_path(oracle_mod, monkeypatch):
-    # voxels that collect more than VOXPROJ_HEAVY_T pixels in a call are summed by a whole workgroup with a
+def test_heavy_voxels_use_the_workgroup_path(oracle_mod, heavy_threshold):
+    # voxels that collect more than VP_OPT_HEAVY_THRESHOLD pixels in a call are summed by a whole workgroup with a
     # fixed summation tree: IDs/counts stay exact, sums within 1e-4 (not bit-identical to the serial order),
     # and two runs agree bit for bit.
     import voxproj_host
-    monkeypatch.setenv("VOXPROJ_HEAVY_T", "6")
+    heavy_threshold(6)
     s = make_scene(2000, 5, 48, 32, seed=31, room=(5.0, 4.0, 2.4))
     for C in (16, 512, 7):
         feats = make_features_np(5, 32, 48, C, seed=31)[None]
@@ -453,9 +453,15 @@ def test_camera_inside_and_next_to_voxels(oracle_mod):
 def test_march_ab_arm_exact_loop_equals_leaping(oracle_mod, monkeypatch):
     s = make_scene(2000, 2, 40, 24, seed=56, room=(5.0, 4.0, 2.4))
     feats = make_features_np(2, 24, 40, 8, seed=56)[None]
-    monkeypatch.setenv("VOXPROJ_EXACT_MARCH", "1")
-    _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
-    monkeypatch.delenv("VOXPROJ_EXACT_MARCH")
+    import project_features_cuda
+    import voxproj_host
+    monkeypatch.setattr(voxproj_host, "EXACT_MARCH", True)
+    project_features_cuda.set_exact_march(True)
+    try:
+        _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
+    finally:
+        project_features_cuda.set_exact_march(False)
+    monkeypatch.setattr(voxproj_host, "EXACT_MARCH", False)
     _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
 
 
@@ -478,12 +484,10 @@ def test_ray_parameter_closed_form_over_many_increments(oracle_mod):
             _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, opts, np.array([-2.1, -1.7, 0.05], np.float32), 0.2, 151)
 
 
-@pytest.mark.parametrize("env", [{}, {"VOXPROJ_FH_LDS_KB": "0"}, {"VOXPROJ_FH_LDS_KB": "80"}])
-def test_pipelined_occupancy_knob_stays_exact(oracle_mod, monkeypatch, env):
-    # the march's occupancy cap in pipelined mode (a dynamic-LDS reservation) is a scheduling hint only
+@pytest.mark.parametrize("lds_kb", [None, 0, 80])
+def test_pipelined_occupancy_knob_stays_exact(oracle_mod, lds_kb):
+    # the march's occupancy cap in pipelined mode (a dynamic-LDS reservation, VP_OPT_MARCH_LDS_KB) is a scheduling hint only
     import voxproj_host
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     s = make_scene(2000, 9, 48, 32, seed=71, room=(5.0, 4.0, 2.4))
     C = 16
     feats = make_features_np(9, 32, 48, C, seed=71)
@@ -498,6 +502,7 @@ def test_pipelined_occupancy_knob_stays_exact(oracle_mod, monkeypatch, env):
     count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
     out_t = torch.zeros(n_rows, C, device=dev)
     ws = voxproj_host.Workspace()
+    ws.set_option(voxproj_host.VP_OPT_MARCH_LDS_KB, lds_kb)
     splits = [(0, 5), (5, 6), (6, 9), (0, 9)]
     vmis = [c2w_t[a:b].reshape(-1).contiguous() for a, b in splits]
     for (a, b), vmi in zip(splits, vmis):
@@ -542,9 +547,9 @@ def test_fp16_feature_maps_give_the_fp32_bits(oracle_mod):
         assert out_t.cpu().numpy().tobytes() == out.tobytes()
 
 
-def test_fp16_heavy_path(oracle_mod, monkeypatch):
+def test_fp16_heavy_path(oracle_mod, heavy_threshold):
     import voxproj_host
-    monkeypatch.setenv("VOXPROJ_HEAVY_T", "6")
+    heavy_threshold(6)
     dev = torch.device(DEV)
     s = make_scene(2000, 4, 48, 32, seed=82, room=(5.0, 4.0, 2.4))
     C = 512
@@ -629,7 +634,7 @@ def test_randomized_differential_against_the_oracle(oracle_mod):
     assert n_hit_cases > 30
 
 
-def test_randomized_job_mode_against_the_oracle(oracle_mod, monkeypatch):
+def test_randomized_job_mode_against_the_oracle(oracle_mod, heavy_threshold):
     # the raw API the way a job drives it: batches of grids (B 1..3), many views per call (up to 70), sequences of
     # pipelined or plain calls accumulating into the same outputs, fp32 or fp16 feature maps, heavy-voxel thresholds
     # low enough to send voxels down the workgroup path, the optional per-view hit counter.  Counts and view counts
@@ -654,7 +659,7 @@ def test_randomized_job_mode_against_the_oracle(oracle_mod, monkeypatch):
         C = int(rng.choice([8, 16, 40]))
         f16 = bool(rng.integers(0, 2))
         pipeline = bool(rng.integers(0, 2))
-        monkeypatch.setenv("VOXPROJ_HEAVY_T", str(int(rng.choice([3, 20, 100000000]))))
+        heavy_threshold(int(rng.choice([3, 20, 100000000])))
         f = float(rng.uniform(0.5, 2.0)) * W
         intr = np.stack([np.array([f, f, W * rng.uniform(0.3, 0.7), H * rng.uniform(0.3, 0.7)], np.float32) for _ in range(B)])
         opts = np.array([W, H, 0.01, float(2.0 * np.linalg.norm(ext)), float(np.float32(vs * rng.uniform(0.3, 1.2)))], np.float32)

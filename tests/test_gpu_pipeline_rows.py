@@ -16,8 +16,8 @@ DEV = "cuda:0"
 
 
 @pytest.fixture(autouse=True)
-def _no_heavy_path_by_default(monkeypatch):
-    monkeypatch.setenv("VOXPROJ_HEAVY_T", "100000000")
+def _no_heavy_path_by_default(heavy_threshold):
+    heavy_threshold(100000000)
 
 
 def test_hip_path_matches_committed_s1_golden():
@@ -447,13 +447,13 @@ def test_entry_point_writes_checkpoints_and_the_feature_ply(tmp_path):
     assert torch.equal(ck["voxel_coords"], fin20["voxel_coords"]) and torch.equal(ck["avg_feats"], fin20["avg_feats"])
 
 
-def test_parity_aggregator_is_bit_exact_with_large_voxels_under_production_settings(oracle_mod, monkeypatch):
+def test_parity_aggregator_is_bit_exact_with_large_voxels_under_production_settings(oracle_mod, heavy_threshold):
     # Cameras a few voxels from a wall: single voxels collect far more than the production heavy threshold (256 + 64
     # pixels for a one-view call).  The parity mode promises the reference's bits (per-view sums rounded to float16,
-    # DPF:252), so it asks the projector for serial sums (VP_FLAG_SERIAL_SUMS) -- no VOXPROJ_HEAVY_T override here.
+    # DPF:252), so it asks the projector for serial sums (VP_FLAG_SERIAL_SUMS) -- no threshold override here.
     from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
     from synthetic_scene import make_features_np, make_scene
-    monkeypatch.delenv("VOXPROJ_HEAVY_T", raising=False)
+    heavy_threshold(None)
     s = make_scene(2000, 4, 96, 64, seed=33, room=(5.0, 4.0, 2.4))
     c2w = s.c2w.copy()
     for v in range(4):                                            # move every camera to 3 voxels from the wall it faces

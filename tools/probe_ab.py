@@ -15,7 +15,7 @@ from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 libs = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
 pipeline = "--pipeline" in sys.argv
 half = "--f16" in sys.argv
-# --heavy-ts=a,b,c: per library also sweep the heavy-voxel threshold (env VOXPROJ_HEAVY_T, read by the library per call; 0 = default)
+# --heavy-ts=a,b,c: per library also sweep the heavy-voxel threshold (VP_OPT_HEAVY_THRESHOLD of the workspace; 0 = default)
 heavy_ts = next(([int(v) for v in a.split("=")[1].split(",")] for a in sys.argv if a.startswith("--heavy-ts=")), [None])
 dev = torch.device("cuda", 0)
 if "--r1" in sys.argv:      # BASELINE config 2
@@ -40,14 +40,11 @@ out = torch.zeros(n_vox + 1, C, dtype=torch.float32, device=dev)
 ref = None
 for rnd in range(3):
     for path, ht in [(p_, h_) for p_ in libs for h_ in heavy_ts]:
-        if ht is not None:
-            if ht:
-                os.environ["VOXPROJ_HEAVY_T"] = str(ht)
-            else:
-                os.environ.pop("VOXPROJ_HEAVY_T", None)
         voxproj_host._lib = None
         voxproj_host.LIB_PATH = path
         ws = voxproj_host.Workspace()
+        if ht is not None:
+            ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, ht or None)
         out.zero_(); count.zero_()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for rep in range(3):

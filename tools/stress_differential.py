@@ -43,10 +43,6 @@ for case in range(N):
     f16 = bool(rng.integers(0, 2)) and C % 8 == 0
     pipeline = bool(rng.integers(0, 2))
     ht = int(rng.choice([3, 10, 50, 0]))
-    if ht:
-        os.environ["VOXPROJ_HEAVY_T"] = str(ht)
-    else:
-        os.environ.pop("VOXPROJ_HEAVY_T", None)
     f = float(rng.uniform(0.4, 2.2)) * W
     intr = np.stack([np.array([f, f * rng.uniform(0.8, 1.25), W * rng.uniform(0.2, 0.8), H * rng.uniform(0.2, 0.8)], np.float32) for _ in range(B)])
     dmin = float(rng.choice([0.0, 0.01, 0.25]))
@@ -57,6 +53,7 @@ for case in range(N):
     views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
     occ_t = torch.from_numpy(occ.astype(np.int64)).to(dev); intr_t = torch.from_numpy(intr).to(dev)
     ws = voxproj_host.Workspace(); keep = []
+    ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, ht or None)
     for call in range(int(rng.integers(1, 4))):
         V = int(rng.choice([1, 2, 3, 7, 8, 9, 20, 66]))
         c2w = np.zeros((B, V, 4, 4), np.float32)
