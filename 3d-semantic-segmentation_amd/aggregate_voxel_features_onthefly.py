@@ -249,16 +249,43 @@ def write_feature_ply(path, xyz_f32, avg_feats_f16):
             f.write(line + "\n")
 
 
+def _npy_layout(path):
+    """(data offset, shape, dtype) of a C-ordered .npy file, or None when it needs numpy's general loader (Fortran order,
+    object arrays, pickles): numpy.lib.format's own header parser, no data read."""
+    from numpy.lib import format as npf
+    with open(path, "rb") as f:
+        major, minor = npf.read_magic(f)
+        read = {(1, 0): npf.read_array_header_1_0, (2, 0): npf.read_array_header_2_0}.get((major, minor))
+        if read is None:
+            return None
+        shape, fortran, dtype = read(f)
+        if fortran or dtype.hasobject:
+            return None
+        return f.tell(), tuple(int(v) for v in shape), dtype
+
+
 class FeatureFeeder:
     """Feeds the .npy feature maps to the GPU ahead of the projector (the reference re-reads each map from disk three times
-    per view through its sub-processes, AGG:248-294).  Worker threads read a file up to ``depth`` views ahead AND stage it in
-    a pinned host buffer (file reads and the staging copy release the GIL); the consumer's thread only issues the
-    host-to-device copy on a copy stream of its own.  Reading view k+2, copying view k+1 over PCIe (3.6 ms for a 199 MB
-    map) and projecting view k then overlap.  Iterating yields ``(index, path, device_tensor [C,h,w])`` in file order; the
-    tensor is ready on torch's current stream.  ``depth = 0`` reads and copies synchronously (same results)."""
+    per view through its sub-processes, AGG:248-294).
 
-    def __init__(self, paths, device, depth=3):
+    A 199 MB map costs 3.7 ms on PCIe (the floor, profiles/r02_bench_prep.json) but 20-40 ms when ONE thread copies it out
+    of the page cache -- the host copy, not the bus, set the pace of the round-2 feeder.  So every file is cut into
+    ``CHUNK``-byte pieces that a pool of I/O threads ``preadv`` STRAIGHT into a pinned staging buffer (no intermediate
+    array; the read releases the GIL), up to ``depth`` views ahead, and the consumer's thread issues the host-to-device copy
+    PER PIECE, in order, on a copy stream of its own as soon as that piece has landed: the bus starts on a map while its
+    tail is still being read, and reading view k+2, copying view k+1 and projecting view k overlap.
+
+    Iterating yields ``(index, path, device_tensor)`` in file order, the tensor shaped and typed like the file's array and
+    ready on torch's current stream.  ``depth = 0`` reads and copies synchronously (same results); files that are not
+    plain C-ordered arrays go through ``numpy.load`` as a whole."""
+
+    CHUNK = 16 << 20
+
+    def __init__(self, paths, device, depth=3, io_threads=None):
         self.paths, self.dev, self.depth = list(paths), torch.device(device), int(depth)
+        if io_threads is None:
+            io_threads = min(8, max(2, len(os.sched_getaffinity(0)) // 2)) if hasattr(os, "sched_getaffinity") else 4
+        self.io_threads = int(io_threads)
 
     def __iter__(self):
         if self.depth <= 0:
@@ -267,36 +294,62 @@ class FeatureFeeder:
             return
         from concurrent.futures import ThreadPoolExecutor
         nbuf = self.depth + 2
-        pinned, copied = [None] * nbuf, [None] * nbuf          # staging buffers and the event of the copy that last read each
+        pinned = [None] * nbuf        # uint8 staging buffers, grown on demand
+        copied = [None] * nbuf        # event of the last H2D copy that read each buffer
 
-        def stage(i):
-            # memory-mapped: the one pass over the file's bytes is the copy into the pinned buffer
-            import warnings
-            m = np.load(self.paths[i], mmap_mode="r")
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")                  # torch warns about the read-only map; it is only read
-                arr = torch.from_numpy(np.asarray(m)) if m.flags.c_contiguous else torch.from_numpy(np.ascontiguousarray(m))
+        def read_piece(fd, view, off, file_off, n):
+            done = 0
+            while done < n:           # preadv may return short
+                got = os.preadv(fd, [view[off + done:off + n]], file_off + done)
+                if got <= 0:
+                    raise IOError("unexpected end of file")
+                done += got
+            return n
+
+        def submit(pool, i):
+            """Queue the reads of file i: (layout, buffer slot, fd, [future per piece]) -- or a whole-array fallback."""
+            lay = _npy_layout(self.paths[i])
             b = i % nbuf
             if copied[b] is not None:
                 copied[b].synchronize()                          # view i - nbuf has left this buffer
-            if pinned[b] is None or pinned[b].shape != arr.shape or pinned[b].dtype != arr.dtype:
-                pinned[b] = torch.empty(arr.shape, dtype=arr.dtype, pin_memory=True)
-            pinned[b].copy_(arr)
-            return pinned[b]
+                copied[b] = None
+            if lay is None:
+                return None, b, None, [pool.submit(lambda p=self.paths[i]: np.ascontiguousarray(np.load(p)))]
+            off0, shape, dtype = lay
+            nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+            if pinned[b] is None or pinned[b].numel() < nbytes:
+                pinned[b] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+            view = memoryview(pinned[b].numpy())
+            fd = os.open(self.paths[i], os.O_RDONLY)
+            futs = [pool.submit(read_piece, fd, view, o, off0 + o, min(self.CHUNK, nbytes - o)) for o in range(0, nbytes, self.CHUNK)]
+            return (shape, dtype, nbytes), b, fd, futs
 
         copy_stream = torch.cuda.Stream(self.dev)
-        with ThreadPoolExecutor(max_workers=min(self.depth, 4)) as pool:
-            pending = [pool.submit(stage, i) for i in range(min(self.depth, len(self.paths)))]
+        with ThreadPoolExecutor(max_workers=self.io_threads) as pool:
+            pending = [submit(pool, i) for i in range(min(self.depth, len(self.paths)))]
             for i, p in enumerate(self.paths):
-                host = pending.pop(0).result()
+                lay, b, fd, futs = pending.pop(0)
                 with torch.cuda.stream(copy_stream):
-                    d = torch.empty(host.shape, dtype=host.dtype, device=self.dev)
-                    d.copy_(host, non_blocking=True)
+                    if lay is None:
+                        host = torch.from_numpy(futs[0].result())
+                        d = host.to(self.dev)                    # pageable: blocking, rare path
+                    else:
+                        shape, dtype, nbytes = lay
+                        raw = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.dev)
+                        o = 0
+                        try:
+                            for f in futs:                       # in order: the bus follows the readers piece by piece
+                                n = f.result()
+                                raw[o:o + n].copy_(pinned[b][o:o + n], non_blocking=True)
+                                o += n
+                        finally:
+                            os.close(fd)
+                        d = raw[:nbytes].view(getattr(torch, np.dtype(dtype).name)).reshape(shape)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
-                copied[i % nbuf] = ev
+                copied[b] = ev
                 if i + self.depth < len(self.paths):             # submitted only now: its buffer's previous copy is recorded
-                    pending.append(pool.submit(stage, i + self.depth))
+                    pending.append(submit(pool, i + self.depth))
                 cur = torch.cuda.current_stream(self.dev)
                 cur.wait_event(ev)
                 d.record_stream(cur)                             # allocated on the copy stream, consumed on this one

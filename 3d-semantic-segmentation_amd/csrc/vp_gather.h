@@ -241,6 +241,32 @@ constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather that take th
 #endif
 #define VP_GATHER_G(VEC) ((VEC) == 8 ? VP_GATHER_G16 : VP_GATHER_G32)
 
+// Output rows are read once and written once per call by the wavefront that owns the voxel: no reuse inside a launch.
+// VP_OUT_NT = 1 makes both accesses non-temporal, like the feature rows (A/B: tools/probe_levels_rr.py).
+#ifndef VP_OUT_NT
+#define VP_OUT_NT 0
+#endif
+__device__ __forceinline__ float4 ld_out4(const float *p)
+{
+#if VP_OUT_NT
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ t = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+__device__ __forceinline__ void st_out4(float *p, float4 v)
+{
+#if VP_OUT_NT
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_ *>(p));
+#else
+    *reinterpret_cast<float4 *>(p) = v;
+#endif
+}
+
 template <int K, int VEC>
 __device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, int cb, int C, int lane)
 {
@@ -250,12 +276,12 @@ __device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, in
             const int ch = (k * 64 + lane) * 8;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 o = (cb + ch < C) ? ld_out4(orow + ch + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 acc.a[k * 8 + h * 4 + 0] = o.x; acc.a[k * 8 + h * 4 + 1] = o.y; acc.a[k * 8 + h * 4 + 2] = o.z; acc.a[k * 8 + h * 4 + 3] = o.w;
             }
         } else if constexpr (VEC == 4) {
             const int ch = (k * 64 + lane) * 4;
-            const float4 o = (cb + ch < C) ? *reinterpret_cast<const float4 *>(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o = (cb + ch < C) ? ld_out4(orow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
             acc.a[k * 4 + 0] = o.x; acc.a[k * 4 + 1] = o.y; acc.a[k * 4 + 2] = o.z; acc.a[k * 4 + 3] = o.w;
         } else {
             const int ch = k * 64 + lane;
@@ -274,12 +300,12 @@ __device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, i
             if (cb + ch < C) {
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    *reinterpret_cast<float4 *>(orow + ch + h * 4) = make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+                    st_out4(orow + ch + h * 4, make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]));
             }
         } else if constexpr (VEC == 4) {
             const int ch = (k * 64 + lane) * 4;
             if (cb + ch < C)
-                *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+                st_out4(orow + ch, make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]));
         } else {
             const int ch = k * 64 + lane;
             if (cb + ch < C) orow[ch] = acc.a[k];
@@ -551,31 +577,6 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
             work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
 }
 
-// Which entry of a size class the w-th wavefront of the class takes.  The list of a class is in ascending ID order, i.e. in
-// the order of the voxels' positions: taken as it stands, the few thousand wavefronts in flight at any moment gather from
-// the SAME few regions of the same views -- a structured set of addresses whose spread over the HBM channels depends on
-// where the driver placed the feature pool (two speed levels, 4.6 % apart alone and up to 12 % pipelined, following the
-// pool's allocation: profiles/r03_levels_*).  A multiplicative permutation of the class scatters the wavefronts in
-// flight over the whole scene; every voxel is still summed by one wavefront in (b,v,y,x) order, so results are unchanged.
-#ifndef VP_WORK_PERMUTE
-#define VP_WORK_PERMUTE 1
-#endif
-__device__ __forceinline__ unsigned class_slot(unsigned w, unsigned n)
-{
-#if VP_WORK_PERMUTE
-    // w -> (w * P) mod n is a bijection of [0, n) whenever gcd(P, n) = 1: P prime and n < P.  Of two primes the one whose
-    // residue (= the stride between consecutive wavefronts) is not within n/16 of 0 or n is taken.
-    if (n < 64u) return w;
-    unsigned long long P = 2654435761ull;
-    const unsigned r = (unsigned)(P % n);
-    if (r < n / 16u || n - r < n / 16u) P = 2246822519ull;
-    return (unsigned)(((unsigned long long)w * P) % n);
-#else
-    (void)n;
-    return w;
-#endif
-}
-
 // MERGED = true: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of 8 or more views); 97 VGPRs,
 // i.e. 4 wavefronts per SIMD -- in pipelined mode a gain, because a fifth gather wave would take the room the next call's
 // march needs (forcing <= 96 registers with __launch_bounds__(256, 5), one allocation: pipelined +2.5 % fp16 / +2 % R1 /
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 #pragma unroll
     for (int k = WORK_CLASSES - 1; k >= 0; k--) {
         const int n = g.work_n[k];
-        if (id == 0 && w < n) id = g.work[(long long)k * p.n_rows + class_slot((unsigned)w, (unsigned)n)];
+        if (id == 0 && w < n) id = g.work[(long long)k * p.n_rows + w];
         w -= n;
     }
     if (id == 0) return;

@@ -58,10 +58,14 @@ def parse():
                          "view of the workload, features resident) instead of raw C-ABI calls; default workload R1")
     ap.add_argument("--entry-pipeline", action="store_true",
                     help="--entry parity: A/B arm, run the one-view calls in the pipelined job mode (VP_FLAG_PIPELINE)")
-    ap.add_argument("--collective", default="reduce", choices=("reduce", "allreduce"),
-                    help="multi-GPU: how the per-rank {sum,count} are combined each pass.  reduce (default) = to rank 0 only, "
-                         "half the xGMI traffic, enough when one rank writes the scene; allreduce = every rank gets the scene")
+    ap.add_argument("--collective", default="allreduce", choices=("reduce", "allreduce"),
+                    help="multi-GPU: how the per-rank {sum,count} are combined each pass.  allreduce (default) = the single RCCL "
+                         "all-reduce north_star names, every rank gets the scene; reduce = to rank 0 only, half the xGMI "
+                         "traffic, enough when one rank writes the scene (what the entry point does)")
     ap.add_argument("--chunk", type=int, default=32, help="views per vp_project_features call")
+    ap.add_argument("--min-calls", type=int, default=4,
+                    help="a rank's views are cut into at least this many calls (when it has that many views), so that the "
+                         "pipelined mode can hide phase 1 of all but the first call")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,8 +90,9 @@ def parse():
                     help="experiment: VP_OPT_HEAVY_THRESHOLD of the workspace (pixels per voxel and call above which a whole "
                          "workgroup sums the voxel); 0 = the library's default, 256 + 64 x views per call")
     ap.add_argument("--no-overlap-reduce", action="store_true",
-                    help="multi-GPU: wait for each pass's all-reduce before starting the next pass (default: the "
-                         "all-reduce of pass k runs on RCCL's stream while pass k+1 is projected into a second buffer)")
+                    help="multi-GPU: skip the extra, overlapped measurement (the collective of pass k on RCCL's stream while "
+                         "pass k+1 is projected into a second buffer; reported under 'overlapped_passes').  The headline "
+                         "value NEVER overlaps passes: a scene is one pass and pays its collective exposed")
     a = ap.parse_args()
     if a.workload is None:
         a.workload = "R1" if a.entry else "R2"
@@ -467,8 +472,8 @@ def main():
     scene = make_scene(n_vox, n_views, W, H, seed=0)
     from view_sharding import reduce_partials, views_of_rank
     my_views = views_of_rank(n_views, rank, world)
-    # at least four calls per rank so that the pipelined mode can hide phase 1 of all but the first call
-    chunk = max(1, min(a.chunk, len(my_views), max(4, -(-len(my_views) // 4))))
+    # at least --min-calls calls per rank so that the pipelined mode can hide phase 1 of all but the first call
+    chunk = max(1, min(a.chunk, len(my_views), max(4, -(-len(my_views) // max(1, a.min_calls)))))
     pool = max(chunk, (min(a.pool, len(my_views)) // chunk) * chunk)
 
     esize = 4 if a.dtype == "f32" else 2
@@ -553,14 +558,15 @@ def main():
     del parked, best, f_try, c_try, o_try
     torch.cuda.empty_cache()
 
-    # multi-GPU: two output buffers, so that the all-reduce of pass k (RCCL's own stream, over xGMI) overlaps the
-    # projection of pass k+1; every reduction is waited for before its buffer is reused and before the timed
-    # region ends
+    # multi-GPU.  The HEADLINE step never overlaps passes: zero, project the rank's views, then the collective, waited for
+    # -- a scene is ONE pass and pays its collective exposed.  The time from "projection done" to "collective done" is
+    # accumulated per step (collective_ms_exposed).  A second, extra measurement after the timed region overlaps the
+    # collective of pass k (RCCL's own stream) with the projection of pass k+1 in a second buffer: what a job that
+    # streams many scenes would see; it is reported under "overlapped_passes", never as `value`.
     bufs = [(out, count)]
-    if dist is not None and not a.no_overlap_reduce:
-        bufs.append((resident((n_rows, C), torch.float32, "output_rows_2").zero_(), resident((n_rows,), torch.int32, "hit_counts_2").zero_()))
-    inflight = [None] * len(bufs)
-    state = {"k": 0}
+    inflight = [None]
+    state = {"k": 0, "exposed_s": 0.0}
+    dst = 0 if a.collective == "reduce" else None
 
     def drain(i=None):
         for j in (range(len(bufs)) if i is None else [i]):
@@ -570,6 +576,20 @@ def main():
                 inflight[j] = None
 
     def step():
+        o, c = bufs[0]
+        c.zero_()
+        o.zero_()
+        for ci in range(len(calls)):
+            one_call(ci, o=o, c=c)
+        if dist is not None:
+            torch.cuda.synchronize(dev)
+            t_proj = time.perf_counter()
+            reduce_partials(dist, [o, c], dst=dst)
+            torch.cuda.synchronize(dev)
+            state["exposed_s"] += time.perf_counter() - t_proj
+        state["k"] += 1
+
+    def step_overlapped():
         i = state["k"] % len(bufs)
         state["k"] += 1
         o, c = bufs[i]
@@ -578,12 +598,7 @@ def main():
         o.zero_()
         for ci in range(len(calls)):
             one_call(ci, o=o, c=c)
-        if dist is not None:
-            dst = 0 if a.collective == "reduce" else None
-            if a.no_overlap_reduce:
-                reduce_partials(dist, [o, c], dst=dst)
-            else:
-                inflight[i] = reduce_partials(dist, [o, c], dst=dst, async_op=True)
+        inflight[i] = reduce_partials(dist, [o, c], dst=dst, async_op=True)
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px, heavy_px = 0, 0, 0, {}, 0, 0
@@ -614,17 +629,18 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    drain()
     barrier()
     voxproj_host.profile_enable(True)
+    state["exposed_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    drain()
     barrier()
     dt = time.perf_counter() - t0
     voxproj_host.workspace_status(ws, dev)
     prof = voxproj_host.profile_read()
+    exposed_ms = state["exposed_s"] / max(1, a.steps) * 1e3
+    reduced = {}      # checksums of the scene for the line (compared across runs by tests/test_gpu_bench_contract.py)
     if dist is None and not os.environ.get("VOXPROJ_BENCH_NOVERIFY"):
         # the timed passes must have produced the same result as the plain pre-pass
         assert int(count.sum().item()) == hit_px, "hit-count total changed between the pre-pass and the timed steps"
@@ -650,15 +666,35 @@ def main():
         dist.all_reduce(t)
         chk = torch.stack([ref_checksum, ref_abs])
         dist.all_reduce(chk)
-        last_o, last_c = bufs[(state["k"] - 1) % len(bufs)]
+        last_o, last_c = bufs[0]
         if rank == 0 or a.collective == "allreduce":
             assert int(last_c.sum().item()) == int(t.item()), "reduced hit counts do not add up to the ranks' totals"
             assert ((last_o.double().sum(0) - chk[0]).abs() <= 1e-6 * chk[1] + 1e-9).all(), \
                 "reduced feature sums differ from the sum of the ranks' single-rank results"
+            reduced = {"reduced_hit_pixels": int(last_c.sum().item()), "reduced_checksum": float(last_o.double().sum().item())}
+    overlapped = None
+    if dist is None:
+        reduced = {"checksum": float(ref_checksum.sum().item()), "checksum_abs": float(ref_abs.sum().item())}
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, exposed_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, exposed_ms = float(t[0].item()), float(t[1].item())
+        if not a.no_overlap_reduce:
+            # extra: passes overlapped with each other's collectives (two output buffers); every reduction is waited for
+            # before its buffer is reused and before the clock stops
+            bufs.append((resident((n_rows, C), torch.float32, "output_rows_2").zero_(), resident((n_rows,), torch.int32, "hit_counts_2").zero_()))
+            inflight.append(None)
+            step_overlapped()
+            drain()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                step_overlapped()
+            drain()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            overlapped = float(t.item()) / a.steps
 
     algo_local = hit_px * C * esize + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
     if dist is not None:
@@ -683,8 +719,8 @@ def main():
             "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} {'fp32' if a.dtype == 'f32' else 'fp16'} feature maps, "
                                    f"room-shell scene seed 0, dmin 0.01 dmax 10 step 0.5*voxel",
                        "views_per_call": chunk, "resident_feature_maps": pool,
-                       "parallelism": (f"views r::{world} per GPU + one RCCL {'reduce to rank 0' if a.collective == 'reduce' else 'all-reduce'} of sum/count per pass"
-                                       + ("" if a.no_overlap_reduce else ", overlapped with the next pass (two output buffers)"))
+                       "parallelism": (f"views r::{world} per GPU + one RCCL {'reduce to rank 0' if a.collective == 'reduce' else 'all-reduce'} of sum/count "
+                                       f"per pass, waited for inside the pass (backend {a.dist_backend})")
                        if world > 1 else "single GPU"},
             "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
             "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
@@ -692,7 +728,16 @@ def main():
                                   "gather": round(prof["gather_ms"] / a.steps, 3),
                                   "gather_heavy": round(prof["heavy_ms"] / a.steps, 3),
                                   "overlapped": pipeline},
-            "pool_placement": placement,
+            "pool_placement": placement, **reduced,
+            **({"collective": {"op": "reduce to rank 0" if a.collective == "reduce" else "all-reduce", "backend": a.dist_backend,
+                               "bytes_per_rank": n_rows * C * 4 + n_rows * 4,
+                               "collective_ms_exposed": round(exposed_ms, 3),
+                               "projection_ms_per_step": round(ms_step - exposed_ms, 3),
+                               "note": "max over ranks; the headline value includes it (no overlap between passes)"},
+                "overlapped_passes": (None if overlapped is None else
+                                      {"ms_per_step": round(overlapped * 1e3, 3), "value": round(n_vox * n_views / overlapped / 1e6, 3),
+                                       "what": "extra: collective of pass k overlapped with the projection of pass k+1 (two output "
+                                               "buffers), what a job streaming many scenes sees; never the headline"})} if world > 1 else {}),
             "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "heavy_pixels_per_step": heavy_px, "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -47,7 +47,10 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
-    assert "reduce to rank 0" in d["config"]["parallelism"]
+    # north_star's collective is the default, named in the line; the headline pays it exposed, the overlapped figure is extra
+    assert "all-reduce" in d["config"]["parallelism"] and d["collective"]["op"] == "all-reduce"
+    assert 0 < d["collective"]["collective_ms_exposed"] < d["ms_per_step"]
+    assert d["overlapped_passes"]["value"] > 0
     assert d["hit_pixels_per_step"] > 0 and d["value"] > 0
 
 
@@ -56,11 +59,35 @@ def test_bench_two_ranks_allreduce_variant():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
-                        "--single-device", "--collective", "allreduce", "--no-overlap-reduce"],
+                        "--single-device", "--collective", "reduce", "--no-overlap-reduce"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]          # bench verifies reduced counts exactly and sums against the ranks' own
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and "all-reduce" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 2 and "reduce to rank 0" in d["config"]["parallelism"] and d["overlapped_passes"] is None
+
+
+def test_bench_two_ranks_at_the_r2_shape():
+    """BASELINE config 4's own workload shape on the one-GPU box: 200k voxels, 968x548x512 fp32 maps, views r::2 (16 per
+    rank, 17.4 GB of maps each), one all-reduce of {sum f32 [200001,512], count} -- over gloo, both ranks on cuda:0.
+    bench.py itself asserts that the reduced hit counts equal the sum of the ranks' single-rank totals EXACTLY and the
+    reduced feature sums, per channel, the sum of the ranks' single-rank checksums; here additionally against a
+    single-rank run of the same 32 views."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    common = ["--workload", "R2", "--views", "32", "--pool", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = _last_json(r1.stdout)
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
+                         "--gpus", "2", "--dist-backend", "gloo", "--single-device", "--no-overlap-reduce"] + common,
+                        capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = _last_json(r2.stdout)
+    assert two["n_gpus"] == 2 and two["config"]["workload"].startswith("R2: 200000 voxels x 32 views x 968x548x512")
+    assert two["collective"]["op"] == "all-reduce" and two["collective"]["bytes_per_rank"] == 200001 * 512 * 4 + 200001 * 4
+    # the scene the two ranks reduced IS the scene one rank projects: hit pixels exactly, channel checksum to fp32 rounding
+    assert two["reduced_hit_pixels"] == one["hit_pixels_per_step"]
+    assert abs(two["reduced_checksum"] - one["checksum"]) <= 1e-6 * one["checksum_abs"]
 
 
 def _check_common(d):

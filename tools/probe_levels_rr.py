@@ -102,14 +102,23 @@ for lp in libs:
 
 # which buffer carries the level: the feature pool, the output rows or the workspace (ID image, tables)?
 cross = []
-print(f"== {os.path.basename(libs[0])}: pool k (rows) x output rows j (columns), workspace 0")
-for k, pool in enumerate(pools):
+for lp in libs:
+    print(f"== {os.path.basename(lp)}: pool k (rows) x output rows j (columns), workspace 0")
+    for k, pool in enumerate(pools):
+        row = []
+        for j in range(len(outs)):
+            g, _ = measure(lp, pool, outs[j][0], outs[j][1], wsd)
+            row.append(g)
+            cross.append({"lib": os.path.basename(lp), "pool": k, "out": j, "ws": 0, "gather_ms": round(g, 4)})
+        print("   pool %d   " % k + "  ".join(f"{g:.3f}" for g in row), flush=True)
+print(f"== {os.path.basename(libs[0])}: pool 0 / output ROWS 0 with the hit-count tensor of set j (columns), twice -- rows or counts?")
+for rep in range(2):
     row = []
     for j in range(len(outs)):
-        g, _ = measure(libs[0], pool, outs[j][0], outs[j][1], wsd)
+        g, _ = measure(libs[0], pools[0], outs[0][0], outs[j][1], wsd)
         row.append(g)
-        cross.append({"pool": k, "out": j, "ws": 0, "gather_ms": round(g, 4)})
-    print("   pool %d   " % k + "  ".join(f"{g:.3f}" for g in row), flush=True)
+        cross.append({"pool": 0, "out": 0, "count": j, "ws": 0, "gather_ms": round(g, 4)})
+    print("   rep %d    " % rep + "  ".join(f"{g:.3f}" for g in row), flush=True)
 print(f"== {os.path.basename(libs[0])}: pool 0 / output rows 0 on workspaces 0..{a.workspaces - 1} (each its own allocation), three times")
 for rep in range(3):
     row = []
