@@ -353,7 +353,13 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
     for (int cb = 0; cb < C; cb += CB) {
         Acc<K, VEC> acc;
         float *orow = g.out + (long long)id * C + cb;
+#if defined(VP_DIAG_NOLOAD)
+        // timing experiment only (tools/probe_levels_rr.py): start from zero instead of the output row -- WRONG sums
+#pragma unroll
+        for (int i_ = 0; i_ < K * VEC; i_++) acc.a[i_] = 0.f;
+#else
         acc_load<K, VEC>(acc, orow, cb, C, lane);
+#endif
         const Acc<K, VEC> acc0 = acc;
         int found = 0, nviews = 0;
         for (int b = 0; b < p.B && found < expected; b++) {
@@ -425,6 +431,9 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
                 nviews += found > before;
             }
         }
+#if defined(VP_DIAG_NOSTORE)
+        if (found == -12345)        // timing experiment only: never true, keeps the sums alive -- outputs are NOT written
+#endif
         acc_store<K, VEC>(acc, orow, cb, C, lane);
         if (cb == 0 && lane == 0) {
             g.count[id] += found;   // K.cu:77 (one add of the per-call total)

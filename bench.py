@@ -112,11 +112,11 @@ def source_digest():
 
 
 def pmc_traffic(workload, chunk, dtype):
-    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json),
+    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json),
     corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
     None unless the profile was taken on this workload / views-per-call / dtype AND with these very kernel sources
     (the file records the digest of csrc/ it was measured on: a stale profile yields null, not a wrong number)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         with open(path) as f:
             prof = json.load(f)
@@ -132,7 +132,7 @@ def pmc_traffic(workload, chunk, dtype):
 
 
 def write_pmc_json(prof_dir, out_path):
-    """profiles/r02_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
+    """profiles/r03_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
     dtype), stamped with the digest of the kernel sources they were measured on."""
     import collections
     import csv
@@ -743,8 +743,13 @@ def main():
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "measured_stream_read_gbs": round(stream_gbs, 1),
                          "frac_of_measured_stream_read": round(ach / stream_gbs, 4) if stream_gbs > 0 else None,
+                         # one-word diagnostic of the placement level this run landed on: the gather
+                         # against the SAME box's plain streaming read -- fast >= 0.98, mid >= 0.93, else slow
+                         "level": (None if stream_gbs <= 0 else "fast" if ach / stream_gbs >= 0.98 else "mid" if ach / stream_gbs >= 0.93 else "slow"),
                          "traffic": (int(pmc_traffic(a.workload, chunk, a.dtype) * len(my_views) / len(calls))
                                      if (not a.views and world == 1 and pmc_traffic(a.workload, chunk, a.dtype)) else None),
+                         "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this build, rescaled to this "
+                                           "run's views per launch; null when the kernel sources changed since) -- not measured in this run",
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)

@@ -1,18 +1,19 @@
 #!/bin/bash
-# copies the summaries of tools/profile_round.sh r02 + tools/run_benches.sh (merged back under gpurun_out/) into profiles/
+tag=${1:-r03}
+# copies the summaries of tools/profile_round.sh $tag + tools/run_benches.sh (merged back under gpurun_out/) into profiles/
 P=profiles
-cp gpurun_out/r02_pmc_traffic.json $P/r02_pmc_traffic.json
-cp gpurun_out/prof_r02/trace/t_kernel_stats.csv $P/r02_kernel_stats.csv; cp gpurun_out/prof_r02/trace_f16/t_kernel_stats.csv $P/r02_kernel_stats_f16.csv; cp gpurun_out/prof_r02/trace_R4/t_kernel_stats.csv $P/r02_kernel_stats_R4.csv
-for n in default f16 R1 R4 entry_parity entry_fast serial; do grep '^{' gpurun_out/r2_bench_$n.log | tail -1 > $P/r02_bench_$n.json; done
-cp gpurun_out/r2_bench_prep.log $P/r02_bench_prep.json; cp gpurun_out/r2_bench_dropin.log $P/r02_bench_dropin.log
-grep '^{' gpurun_out/prof_r02/bench_under_rocprof.log | tail -1 > $P/r02_bench_under_rocprof.json
-{ echo "# rocprofv3 summaries, round 2, final build (MI355X, ROCm 7.2), produced by tools/profile_round.sh r02 + tools/summarize_prof.py"
+cp gpurun_out/${tag}_pmc_traffic.json $P/${tag}_pmc_traffic.json
+cp gpurun_out/prof_$tag/trace/t_kernel_stats.csv $P/${tag}_kernel_stats.csv; cp gpurun_out/prof_$tag/trace_f16/t_kernel_stats.csv $P/${tag}_kernel_stats_f16.csv; cp gpurun_out/prof_$tag/trace_R4/t_kernel_stats.csv $P/${tag}_kernel_stats_R4.csv
+for n in default f16 R1 R4 entry_parity entry_parity_pipelined entry_fast serial; do grep '^{' gpurun_out/${tag}_bench_$n.log | tail -1 > $P/${tag}_bench_$n.json; done
+cp gpurun_out/${tag}_bench_prep.log $P/${tag}_bench_prep.json; cp gpurun_out/${tag}_bench_dropin.log $P/${tag}_bench_dropin.log
+grep '^{' gpurun_out/prof_$tag/bench_under_rocprof.log | tail -1 > $P/${tag}_bench_under_rocprof.json
+{ echo "# rocprofv3 summaries, round ${tag#r0}, final build (MI355X, ROCm 7.2), produced by tools/profile_round.sh $tag + tools/summarize_prof.py"
   echo "# commands (cd \$GRAFT_REPO_ROOT; TMPDIR=/tmp):"
-  echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace     -- python3 bench.py --no-cpu-baseline              (same run's JSON line: profiles/r02_bench_under_rocprof.json)"
+  echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace     -- python3 bench.py --no-cpu-baseline              (same run's JSON line: profiles/${tag}_bench_under_rocprof.json)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_f16 -- python3 bench.py --no-cpu-baseline --dtype f16"
   echo "#   rocprofv3 --pmc FETCH_SIZE -d <out>/fetch_<dt> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 128 [--dtype f16]"
   echo "#   rocprofv3 --pmc WRITE_SIZE -d <out>/write_<dt> -- (same)      (separate passes; counter passes serialise kernels: their durations are not the bench's)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_R4  -- python3 bench.py --workload R4 --no-cpu-baseline"
   echo "# k_gather averages over ALL launches of a process (placement pass 20, pre-pass 10, warm-up 10, timed 30, after-pass 20 = 90);"
-  echo "# FETCH_SIZE is in KB and counts 64 B per 128-B request for 16-B-per-lane streaming reads on gfx950 -> doubled in profiles/r02_pmc_traffic.json's reader"
-  cat gpurun_out/prof_r02/summary.txt | cut -c1-420; } > $P/r02_rocprofv3_summary.txt
+  echo "# FETCH_SIZE is in KB and counts 64 B per 128-B request for 16-B-per-lane streaming reads on gfx950 -> doubled in profiles/${tag}_pmc_traffic.json's reader"
+  cat gpurun_out/prof_$tag/summary.txt | cut -c1-420; } > $P/${tag}_rocprofv3_summary.txt

@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel trace + stats of the default bench command, FETCH_SIZE / WRITE_SIZE passes
 # (separate, as MI355X_MICROARCH.md prescribes), fp32 and fp16.  Run on the GPU box from the repo root:
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
