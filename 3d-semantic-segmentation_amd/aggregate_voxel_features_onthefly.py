@@ -52,10 +52,13 @@ _NEVER = 2 ** 30
 class VoxelFeatureAggregator:
     """Running per-voxel aggregate over views, resident on one GPU."""
 
-    def __init__(self, occ_zyx, grid_origin, voxel_size, channels, mode="parity", device="cuda", parity_pipeline=False):
+    def __init__(self, occ_zyx, grid_origin, voxel_size, channels, mode="parity", device="cuda", parity_pipeline=True):
         self.dev = torch.device(device)
         self.mode = mode
-        self.parity_pipeline = bool(parity_pipeline)     # A/B: VP_FLAG_PIPELINE for the one-view calls of the parity mode
+        # VP_FLAG_PIPELINE for the one-view calls of the parity mode too: the march of view k+1 under the gather and the
+        # fp16 epilogue of view k -- 0.124 vs 0.159 ms per R1 view (profiles/r03_bench_entry_parity*.json; round 2 measured
+        # the opposite with a host synchronisation per call in the way, ADVICE r2)
+        self.parity_pipeline = bool(parity_pipeline)
         self._intr_dev = {}                              # intrinsics already on the device, by value
         self._copy_stream = None
         self.occ3 = occ_zyx.to(self.dev).contiguous()
@@ -137,18 +140,19 @@ class VoxelFeatureAggregator:
             # (AGG:309-312), views += 1 (AGG:313), first_view for the dict order; the epilogue leaves the scratch pair
             # zeroed, so nothing of size [n_rows, C] is filled, cast or blended per view.  Everything is queued on the
             # current stream; nothing blocks until flush().
+            # poses and intrinsics are read by the library's side stream, which torch's allocator knows nothing about: they
+            # are kept alive until the next flush.  The feature maps are read on the caller's stream only, where torch's
+            # stream-ordered reuse is safe, so they are not held.
             self._keep = getattr(self, "_keep", [])
             vmis = c2w.reshape(V, 16)
-            self._keep.append((feats, vmis, intr))
-            self._kept_bytes = getattr(self, "_kept_bytes", 0) + feats.numel() * feats.element_size()
+            self._keep.append((vmis, intr))
             if self.n_seen + V > self._nonfinite.numel():
                 self.flush()
                 grown = torch.zeros(2 * (self.n_seen + V), dtype=torch.int32, device=self.dev)
                 grown[:self._nonfinite.numel()] = self._nonfinite
                 self._nonfinite = grown
-            # plain asynchronous calls (with one view per call the kernels are short: the extra stream and event traffic of
-            # the pipelined job mode costs more than the overlap returns, measured 0.23 vs 0.20 ms/view), through a call
-            # object that binds everything constant once -- the host side of a view is two foreign calls
+            # asynchronous calls through a call object that binds everything constant once -- the host side of a view is two
+            # foreign calls
             key = (H, W, ikey if ikey is not None else intr.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
             if getattr(self, "_prep_key", None) != key:
                 self.flush()
@@ -163,18 +167,18 @@ class VoxelFeatureAggregator:
                 voxproj_host.aggregate_view_f16(self._sum, self._cnt, self.run16, self.views, self.first_view,
                                                 self.n_seen, self._nonfinite, self.n_seen, stream=self._prep.stream)
                 self.n_seen += 1
-            if len(self._keep) > 256 or self._kept_bytes > (8 << 30):
+            if len(self._keep) > 256:
                 self.flush()
         else:
-            # keep every argument of a pipelined call alive until the stream is drained
+            # keep what the library's side stream reads alive until the streams are drained (see the parity branch)
             self._keep = getattr(self, "_keep", [])
             vmi = c2w.reshape(-1)
-            self._keep.append((feats, vmi, intr))
+            self._keep.append((vmi, intr))
             voxproj_host.project_features_raw(feats.unsqueeze(0), self.occ, vmi, intr, self._opts(W, H), self.count,
                                               self.sum32, self.grid_origin, self.voxel_size, workspace=self.ws,
                                               sync=False, reuse_accel=None, pipeline=True, views_hit=self.views)
             self.n_seen += V
-            if len(self._keep) > 4:
+            if len(self._keep) > 64:
                 self.flush()
 
     def flush(self):
@@ -183,7 +187,6 @@ class VoxelFeatureAggregator:
         if self.ws.buf is not None:
             voxproj_host.workspace_status(self.ws, self.dev)
         self._keep = []
-        self._kept_bytes = 0
         if self.mode == "parity" and self.n_seen > self._reported:
             bad = torch.nonzero(self._nonfinite[self._reported:self.n_seen]).reshape(-1).tolist()
             for v in bad:
@@ -249,6 +252,20 @@ def write_feature_ply(path, xyz_f32, avg_feats_f16):
             f.write(line + "\n")
 
 
+def _granted_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup quota (a one-GPU box of the pool shows 256
+    logical CPUs and grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _npy_layout(path):
     """(data offset, shape, dtype) of a C-ordered .npy file, or None when it needs numpy's general loader (Fortran order,
     object arrays, pickles): numpy.lib.format's own header parser, no data read."""
@@ -284,7 +301,7 @@ class FeatureFeeder:
     def __init__(self, paths, device, depth=3, io_threads=None):
         self.paths, self.dev, self.depth = list(paths), torch.device(device), int(depth)
         if io_threads is None:
-            io_threads = min(8, max(2, len(os.sched_getaffinity(0)) // 2)) if hasattr(os, "sched_getaffinity") else 4
+            io_threads = max(2, min(16, _granted_cpus() - 2))     # a page-cache read is a memcpy: ~3 GB/s per thread
         self.io_threads = int(io_threads)
 
     def __iter__(self):
@@ -415,7 +432,20 @@ def main(argv=None):
     by_name, cams = ptd.load_camera_params(args.cam_params)
 
     agg, idx = None, 0
-    batch_f, batch_c, batch_intr = [], [], None
+    # Views are up-sampled STRAIGHT into a slot of a small ring of call-sized device buffers [per_call, H, W, C] (round 2
+    # stacked the per-view tensors: an extra pass over 1 GB per view and a fresh 8 GB allocation per call).  Stream order
+    # keeps a slot safe: the up-sample that refills it is queued on the same stream behind the gather that read it.
+    per_call = 1 if args.mode == "parity" else max(1, args.views_per_call)
+    ring, ring_key, slot, fill = None, None, 0, 0
+    batch_c, batch_intr = [], None
+    keep_dtype = args.half_features and args.mode == "fast"
+
+    def submit():
+        nonlocal slot, fill, batch_c
+        if fill:
+            agg.add_views(ring[slot][:fill], torch.stack(batch_c), batch_intr)
+            slot, fill, batch_c = (slot + 1) % len(ring), 0, []
+
     from view_sharding import views_of_rank
     mine = [feature_files[i] for i in views_of_rank(len(feature_files), rank, world)]
     usable = [f for f in mine if by_name.get(os.path.basename(f)[:-4]) is not None]
@@ -429,30 +459,33 @@ def main(argv=None):
         entry = by_name[name]
         H0, W0 = _image_size(entry, cams, args.images_dir, name)
         H_new, W_new = int(H0 * args.downsample_factor), int(W0 * args.downsample_factor)          # AGG:215
-        feats = ptd.upsample_features(raw, (H_new, W_new), device=dev,                             # PTD:115-127
-                                      keep_dtype=(args.half_features and args.mode == "fast"))
         intr, c2w = ptd.camera_for(entry, cams, args.downsample_factor)                            # PTD:132-172
+        C_in = int(raw.shape[0])
+        dt = torch.float16 if (keep_dtype and raw.dtype == torch.float16) else torch.float32
+        key = (H_new, W_new, C_in, dt)
         if agg is None:
-            agg = VoxelFeatureAggregator(occ, grid_origin, voxel_size, feats.shape[-1], args.mode, dev)
-        same = bool(batch_f) and torch.equal(batch_intr, intr) and batch_f[0].shape == feats.shape
-        if batch_f and (not same or len(batch_f) >= (1 if args.mode == "parity" else args.views_per_call)):
-            agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
-            batch_f, batch_c = [], []
-        batch_f.append(feats)
+            agg = VoxelFeatureAggregator(occ, grid_origin, voxel_size, C_in, args.mode, dev)
+        if key != ring_key or (fill and not torch.equal(batch_intr, intr)) or fill >= per_call:
+            submit()
+        if key != ring_key:
+            if ring is not None:
+                agg.flush()                                        # the old ring's calls are done before it goes away
+            ring = [torch.empty((per_call, H_new, W_new, C_in), dtype=dt, device=dev) for _ in range(2 if per_call > 1 else 3)]
+            ring_key, slot = key, 0
+        ptd.upsample_features(raw, (H_new, W_new), device=dev, keep_dtype=keep_dtype, out=ring[slot][fill])   # PTD:115-127
+        fill += 1
         batch_c.append(c2w)
         batch_intr = intr
         idx = k + 1
         # AGG:318-352: a consolidated checkpoint every 20 views (single process: with several ranks no rank holds the
         # scene before the final reduction, and the reference has no resume path that would read these files)
         if world == 1 and idx % CHECKPOINT_EVERY == 0:
-            agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
-            batch_f, batch_c = [], []
+            submit()
             r = agg.result(xyz_dtype=np.float64)
             torch.save({k2: r[k2] for k2 in ("xyz", "avg_feats", "hit_count", "voxel_coords")},
                        os.path.join(args.checkpoint_dir, f"checkpoint_features_{idx}.pt"))
             print(f"[CHECKPOINT] Saved consolidated checkpoint data after {idx} images")
-    if batch_f:
-        agg.add_views(torch.stack(batch_f), torch.stack(batch_c), batch_intr)
+    submit()
     if world > 1:
         # every rank must reach the all-reduce: agree first that each of them had something to project
         ok = torch.tensor([int(agg is not None)], device=dev)

@@ -542,9 +542,12 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
 
 // Work list of a call: the voxels that received pixels (and are not heavy), binned by size class -- class k holds the
 // voxels with floor(log2(pixels)) == k + 3 (clamped to 0 .. WORK_CLASSES-1).  k_gather walks the classes from the largest
-// down, so the long voxels start first and the short ones fill the tail (longest-processing-time-first), and no
-// wavefront is launched for the voxels the call did not touch at all.  Inside a class the IDs keep roughly their
-// ascending order (neighbouring voxels read neighbouring pixels).  One lane per ID, appends aggregated per wavefront.
+// down, so the long voxels start first and the short ones fill the tail (longest-processing-time-first).  The grid is
+// still sized for every row (the host does not know how many voxels a call touches): the wavefronts beyond the end of the
+// list read the eight class counters and exit -- no box, no ID image, no output row is touched for an untouched voxel.
+// Inside a class the IDs keep roughly their ascending order (neighbouring voxels read neighbouring pixels).  One lane per
+// ID, appends aggregated per workgroup.  (Each class has room for every row -- 8 x n_rows ints per buffer set, 64 B of
+// workspace per voxel row -- because the class sizes are only known once every workgroup has counted.)
 constexpr int WL_PER_THREAD = 16;   // IDs per lane of k_worklist: a 256-thread workgroup bins 4096 voxel IDs
 
 __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, long long n_rows,

@@ -5,7 +5,7 @@ Workload (BASELINE.json metric config, "R2"): 200 000 occupied voxels x 300 view
 synthetic feature maps (SURVEY.md section 8d generator, seed 0).  One STEP = one pass of the hot path
 over the whole scene: every view's feature map is read from HBM exactly once, in calls of --chunk views
 through the C-ABI (vp_project_features), features already resident in HBM.  326 GB of feature maps do
-not fit one GPU, so a pool of --pool distinct maps (default 32 = 34.8 GB, far beyond the 256 MiB Infinity
+not fit one GPU, so a pool of --pool distinct maps (default: one call's worth, 30 maps = 32.6 GB, far beyond the 256 MiB Infinity
 Cache) is cycled; the rays, the voxel assignment and the bytes moved are those of 300 distinct views.
 
 Set-up, untimed: the pool and the output rows are allocated --pool-tries times and the placement with the fastest
@@ -62,10 +62,15 @@ def parse():
                     help="multi-GPU: how the per-rank {sum,count} are combined each pass.  allreduce (default) = the single RCCL "
                          "all-reduce north_star names, every rank gets the scene; reduce = to rank 0 only, half the xGMI "
                          "traffic, enough when one rank writes the scene (what the entry point does)")
-    ap.add_argument("--chunk", type=int, default=32, help="views per vp_project_features call")
-    ap.add_argument("--min-calls", type=int, default=4,
-                    help="a rank's views are cut into at least this many calls (when it has that many views), so that the "
-                         "pipelined mode can hide phase 1 of all but the first call")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="views per vp_project_features call; 0 (default) = as many as hold --call-gb of feature maps (R2 fp32: "
+                         "32, R2 fp16: 64, R1: all 100 in one call), then evened out over the rank's calls")
+    ap.add_argument("--call-gb", type=float, default=35.0,
+                    help="feature-map bytes per call the automatic --chunk aims for: launches of ~5 ms amortise ramp-up and tail, "
+                         "and the touched output rows are read-modify-written once per call")
+    ap.add_argument("--min-calls", type=int, default=1,
+                    help="cut a rank's views into at least this many calls (experiment; in pipelined mode the march of every call "
+                         "but the first hides under the previous gather)")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -123,7 +128,8 @@ def pmc_traffic(workload, chunk, dtype):
     except OSError:
         return None
     run = prof.get("runs", {}).get(dtype)
-    if run is None or (prof.get("workload"), prof.get("views_per_call")) != (workload, chunk):
+    # the profile's launches may hold a few views more or fewer than this run's (the per-view figure is what is used)
+    if run is None or prof.get("workload") != workload or abs(prof.get("views_per_call", 0) - chunk) > 4:
         return None
     if prof.get("source_digest") != source_digest():
         return None
@@ -244,7 +250,7 @@ def bench_colors(a, dev, rank, world, dist):
     N, V, W, H = 500000, a.views or 1000, 1752, 1168
     s = make_scene(N, V, W, H, seed=0)
     my_views = views_of_rank(V, rank, world)
-    chunk = max(1, min(a.chunk if a.chunk != 32 else 1000, len(my_views)))     # default: the rank's views in one call (6.1 GB of images)
+    chunk = max(1, min(a.chunk if a.chunk > 0 else 1000, len(my_views)))     # default: the rank's views in one call (6.1 GB of images)
     pool = chunk
     occ = torch.from_numpy(s.occ).to(dev)
     gen = torch.Generator(device=dev); gen.manual_seed(0)
@@ -341,7 +347,7 @@ def bench_entry(a, dev, rank, world, dist):
     intr4 = torch.from_numpy(s.intr)
     agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, C, a.entry, dev,
                                  parity_pipeline=a.entry_pipeline)
-    per_call = 1 if a.entry == "parity" else max(1, min(8, a.chunk))
+    per_call = 1 if a.entry == "parity" else max(1, min(8, a.chunk or 8))
     calls = [my_views[i:i + per_call] for i in range(0, len(my_views), per_call)]
     # the poses of every call, on the device and READY before the first call (a pipelined call's side stream reads them
     # without waiting for the caller's stream: an index kernel still pending there would be a contract violation)
@@ -472,11 +478,13 @@ def main():
     scene = make_scene(n_vox, n_views, W, H, seed=0)
     from view_sharding import reduce_partials, views_of_rank
     my_views = views_of_rank(n_views, rank, world)
-    # at least --min-calls calls per rank so that the pipelined mode can hide phase 1 of all but the first call
-    chunk = max(1, min(a.chunk, len(my_views), max(4, -(-len(my_views) // max(1, a.min_calls)))))
-    pool = max(chunk, (min(a.pool, len(my_views)) // chunk) * chunk)
-
     esize = 4 if a.dtype == "f32" else 2
+    # views per call: --chunk, or as many as hold --call-gb of maps; then the rank's views are spread evenly over its calls
+    chunk = a.chunk if a.chunk > 0 else max(1, int(round(a.call_gb * 1e9 / (H * W * C * esize))))
+    chunk = max(1, min(chunk, len(my_views)))
+    n_calls = max(-(-len(my_views) // chunk), min(a.min_calls, len(my_views)))
+    chunk = -(-len(my_views) // n_calls)
+    pool = max(chunk, (min(max(a.pool, chunk), len(my_views)) // chunk) * chunk)
 
     alloc_kind = {}
 
