@@ -387,7 +387,11 @@ def _image_size(entry, cams, images_dir, name):
     return int(cam["height"]), int(cam["width"])
 
 
-def main(argv=None):
+def main(argv=None, timing=None):
+    """``timing``: optional dict that receives ``loop_s`` (wall time of the per-view loop: first file requested to last
+    projector call drained) and ``views`` -- what tools/bench_entry_files.py reports per view, free of the PLY parse and of
+    writing the result files."""
+    import time
     ap = argparse.ArgumentParser(description="Aggregate voxel features pipeline")
     ap.add_argument("--first_only", action="store_true", help="Only process the first input image for debug")
     ap.add_argument("--mode", choices=("parity", "fast"), default="parity")
@@ -453,6 +457,7 @@ def main(argv=None):
         if by_name.get(os.path.basename(f)[:-4]) is None:
             print(f"[ERROR] No camera entry for {os.path.basename(f)[:-4]}")
     position = {f: k for k, f in enumerate(mine)}                  # idx counts every file, as AGG:316 does
+    t_loop = time.perf_counter()
     for _, fpath, raw in FeatureFeeder(usable, dev, args.prefetch):
         k = position[fpath]
         name = os.path.basename(fpath)[:-4]
@@ -486,6 +491,10 @@ def main(argv=None):
                        os.path.join(args.checkpoint_dir, f"checkpoint_features_{idx}.pt"))
             print(f"[CHECKPOINT] Saved consolidated checkpoint data after {idx} images")
     submit()
+    if timing is not None:
+        if agg is not None:
+            agg.flush()
+        timing.update(loop_s=time.perf_counter() - t_loop, views=len(usable))
     if world > 1:
         # every rank must reach the all-reduce: agree first that each of them had something to project
         ok = torch.tensor([int(agg is not None)], device=dev)

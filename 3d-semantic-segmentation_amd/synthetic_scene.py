@@ -139,14 +139,16 @@ def make_features_np(n_views, height, width, channels, seed=0):
     return out
 
 
-def make_features_torch(n_views, height, width, channels, device, seed=0, out=None):
-    """float32 [V,H,W,C] unit vectors generated on ``device`` (one generator seed per view)."""
+def make_features_torch(n_views, height, width, channels, device, seed=0, out=None, view_ids=None):
+    """float32 [V,H,W,C] unit vectors generated on ``device`` (one generator seed per view).  ``view_ids``: the view
+    index each of the V maps is seeded with (default 0 .. V-1), so that a rank holding views r, r+G, ... generates the
+    very maps a single process holds for them."""
     import torch
     if out is None:
         out = torch.empty((n_views, height, width, channels), dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
     for v in range(n_views):
-        gen.manual_seed(seed * 100003 + v)
+        gen.manual_seed(seed * 100003 + (v if view_ids is None else int(view_ids[v])))
         f = out[v]
         f.normal_(generator=gen)
         f /= f.norm(dim=-1, keepdim=True)

@@ -496,14 +496,19 @@ def main():
         alloc_kind[what] = kind
         return t
 
+    # which synthetic map sits in which pool slot: when the pool holds ALL of the rank's views, slot j holds the map of the
+    # rank's j-th view (seeded by its global view index), so a sharded run reads exactly the maps a single process reads
+    # for the same scene; a cycled pool (fewer maps than views) holds maps 0 .. pool-1
+    map_ids = list(my_views[:pool]) if pool >= len(my_views) else list(range(pool))
+
     def alloc_pool():
         if a.dtype == "f32":
             f = resident((1, pool, H, W, C), torch.float32, "feature_pool")
-            make_features_torch(pool, H, W, C, dev, seed=0, out=f[0])
+            make_features_torch(pool, H, W, C, dev, seed=0, out=f[0], view_ids=map_ids)
         else:
             f = resident((1, pool, H, W, C), torch.float16, "feature_pool")
             for v in range(pool):
-                f[0, v] = make_features_torch(1, H, W, C, dev, seed=v)[0].half()
+                f[0, v] = make_features_torch(1, H, W, C, dev, seed=0, view_ids=[map_ids[v]])[0].half()
         return f
 
     occ = torch.from_numpy(scene.occ[None].astype(np.int64)).to(dev)

@@ -73,7 +73,8 @@ def test_bench_two_ranks_at_the_r2_shape():
     reduced feature sums, per channel, the sum of the ranks' single-rank checksums; here additionally against a
     single-rank run of the same 32 views."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    common = ["--workload", "R2", "--views", "32", "--pool", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    # every run's pool holds all of its views (32 maps for the single rank, 16 per rank), so view v reads the map seeded by v in both
+    common = ["--workload", "R2", "--views", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-3000:]
     one = _last_json(r1.stdout)

@@ -46,11 +46,15 @@ try:
     res = {"views": N, "voxels": s.n_vox, "map": [C, h, w], "working_resolution": [584, 876]}
     common = ["--lseg_dir", lseg, "--cam_params", cam_json, "--voxel_ply", ply]
     agg.main(["--mode", "fast", "--checkpoint_dir", os.path.join(tmp, "warm"), "--max_images", "2"] + common)     # warm-up, page cache
+    loops = {}
+
     def run(mode, pf, n, out):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        agg.main(["--mode", mode, "--checkpoint_dir", out, "--prefetch", str(pf), "--max_images", str(n)] + common)
+        tm = {}
+        agg.main(["--mode", mode, "--checkpoint_dir", out, "--prefetch", str(pf), "--max_images", str(n)] + common, timing=tm)
         torch.cuda.synchronize()
+        loops[(mode, pf, n)] = tm
         return time.perf_counter() - t0
 
     for mode in ("parity", "fast"):
@@ -60,6 +64,10 @@ try:
             t = run(mode, pf, N, out)
             res[f"{mode}_prefetch{pf}_ms_per_view"] = round((t - few) / (N - max(2, N // 4)) * 1e3, 2)
             res[f"{mode}_prefetch{pf}_total_s"] = round(t, 2)
+            # the per-view loop alone (first file requested .. last call drained): no PLY parse, no result files -- the
+            # difference figure above also carries the result files, whose size grows with the views
+            tm = loops[(mode, pf, N)]
+            res[f"{mode}_prefetch{pf}_loop_ms_per_view"] = round(tm["loop_s"] / tm["views"] * 1e3, 2)
         a = torch.load(os.path.join(tmp, f"{mode}_0", f"ALL_nonzero_voxel_features_{N}_vox{s.n_vox}.pt"))
         b = torch.load(os.path.join(tmp, f"{mode}_3", f"ALL_nonzero_voxel_features_{N}_vox{s.n_vox}.pt"))
         res[f"{mode}_same_result"] = bool(torch.equal(a["avg_feats"], b["avg_feats"]) and torch.equal(a["voxel_coords"], b["voxel_coords"]))

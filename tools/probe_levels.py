@@ -33,6 +33,7 @@ ap.add_argument("--windows", default="1,4,16,0")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--tag", default="levels")
 ap.add_argument("--f16", action="store_true")
+ap.add_argument("--out-dir", default="levels", help="sub-directory of gpurun_out/ for the JSON")
 a = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -136,8 +137,8 @@ for k, pool in enumerate(pools):
     rows.append(rec)
     print(json.dumps(rec), flush=True)
 
-os.makedirs(os.path.join(ROOT, "gpurun_out", "levels"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "levels", a.tag + ".json"), "w") as f:
+os.makedirs(os.path.join(ROOT, "gpurun_out", a.out_dir), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", a.out_dir, a.tag + ".json"), "w") as f:
     json.dump({"argv": sys.argv[1:], "bytes_per_call": bytes_of, "allocs": rows, "schedule": schedule,
                "when": time.strftime("%Y-%m-%d %H:%M:%S")}, f)
 ws.release()
