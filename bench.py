@@ -5,7 +5,7 @@ Workload (BASELINE.json metric config, "R2"): 200 000 occupied voxels x 300 view
 synthetic feature maps (SURVEY.md section 8d generator, seed 0).  One STEP = one pass of the hot path
 over the whole scene: every view's feature map is read from HBM exactly once, in calls of --chunk views
 through the C-ABI (vp_project_features), features already resident in HBM.  326 GB of feature maps do
-not fit one GPU, so a pool of --pool distinct maps (default: one call's worth, 30 maps = 32.6 GB, far beyond the 256 MiB Infinity
+not fit one GPU, so a pool of --pool distinct maps (default: one call's worth, 60 maps = 65 GB, far beyond the 256 MiB Infinity
 Cache) is cycled; the rays, the voxel assignment and the bytes moved are those of 300 distinct views.
 
 Set-up, untimed: the pool and the output rows are allocated --pool-tries times and the placement with the fastest
@@ -64,13 +64,14 @@ def parse():
                          "traffic, enough when one rank writes the scene (what the entry point does)")
     ap.add_argument("--chunk", type=int, default=0,
                     help="views per vp_project_features call; 0 (default) = as many as hold --call-gb of feature maps (R2 fp32: "
-                         "32, R2 fp16: 64, R1: all 100 in one call), then evened out over the rank's calls")
-    ap.add_argument("--call-gb", type=float, default=35.0,
-                    help="feature-map bytes per call the automatic --chunk aims for: launches of ~5 ms amortise ramp-up and tail, "
-                         "and the touched output rows are read-modify-written once per call")
-    ap.add_argument("--min-calls", type=int, default=1,
-                    help="cut a rank's views into at least this many calls (experiment; in pipelined mode the march of every call "
-                         "but the first hides under the previous gather)")
+                         "60, R2 fp16: 100, R1: 50), then evened out over the rank's calls")
+    ap.add_argument("--call-gb", type=float, default=66.0,
+                    help="feature-map bytes per call the automatic --chunk aims for (SURVEY 8d: chunks of <= 64 resident views, "
+                         "69.5 GB).  Every call read-modify-writes the output rows it touches, and those stores cost far more "
+                         "than their bytes (DESIGN.md section 4): 60 views per call instead of 30 = +2.7 % on a slow-level box")
+    ap.add_argument("--min-calls", type=int, default=2,
+                    help="cut a rank's views into at least this many calls (in pipelined mode the march of every call but the "
+                         "first hides under the previous gather)")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,14 +156,14 @@ def write_pmc_json(prof_dir, out_path):
                     if k:
                         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if "k_gather" in per:
-            # full 32-view launches only (--views 128 = four of them per pass; the pre-pass and the placement pass repeat them)
+            # full 60-view launches only (--views 120 = two of them per pass; the pre-pass and the placement pass repeat them)
             runs[dt] = {k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), 1),
                             "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]), 1)} for k, v in per.items()}
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --views 128 [--dtype f16], MI355X (tools/profile_round.sh)",
+                     "--no-cpu-baseline --views 120 --chunk 60 [--dtype f16], MI355X (tools/profile_round.sh)",
            "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane streaming reads -> doubled by the reader "
                    "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; units KB",
-           "workload": "R2", "views_per_call": 32, "source_digest": source_digest(), "runs": runs}
+           "workload": "R2", "views_per_call": 60, "source_digest": source_digest(), "runs": runs}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
     return doc

@@ -11,7 +11,7 @@ grep '^{' gpurun_out/prof_$tag/bench_under_rocprof.log | tail -1 > $P/${tag}_ben
   echo "# commands (cd \$GRAFT_REPO_ROOT; TMPDIR=/tmp):"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace     -- python3 bench.py --no-cpu-baseline              (same run's JSON line: profiles/${tag}_bench_under_rocprof.json)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_f16 -- python3 bench.py --no-cpu-baseline --dtype f16"
-  echo "#   rocprofv3 --pmc FETCH_SIZE -d <out>/fetch_<dt> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 128 [--dtype f16]"
+  echo "#   rocprofv3 --pmc FETCH_SIZE -d <out>/fetch_<dt> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 120 --chunk 60 [--dtype f16]"
   echo "#   rocprofv3 --pmc WRITE_SIZE -d <out>/write_<dt> -- (same)      (separate passes; counter passes serialise kernels: their durations are not the bench's)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_R4  -- python3 bench.py --workload R4 --no-cpu-baseline"
   echo "# k_gather averages over ALL launches of a process (placement pass 20, pre-pass 10, warm-up 10, timed 30, after-pass 20 = 90);"
