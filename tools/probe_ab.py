@@ -1,7 +1,7 @@
 """A/B of two builds of libvoxproj.so on the SAME feature-pool allocation (its placement moves the gather's speed by
 several per cent, so builds cannot be compared across processes): python tools/probe_ab.py libA.so libB.so [...]
 Prints mean k_gather / k_first_hit time per launch, serial phases (--pipeline: pipelined), R2 scene with 16 views per
-call (--r1: the R1 scene, 25 views per call; --f16: fp16 feature maps)."""
+call (--r1: the R1 scene, 25 views per call; --f16: fp16 feature maps; --v=N: N views per call)."""
 import os
 import sys
 
@@ -24,6 +24,11 @@ if "--r1" in sys.argv:      # BASELINE config 2
 else:
     n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
     V, NCALL = 16, 8
+# --v=N: views per call (the pool holds N maps; calls cycle through the scene's poses)
+for _a in sys.argv:
+    if _a.startswith("--v="):
+        V = int(_a.split("=")[1])
+        NCALL = max(2, min(NCALL, n_views // V))
 s = make_scene(n_vox, n_views, W, H, seed=0)
 occ = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev)
 c2w = torch.from_numpy(s.c2w).to(dev)
