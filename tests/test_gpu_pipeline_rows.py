@@ -570,11 +570,21 @@ def test_feature_feeder_delivers_every_map_in_order(tmp_path):
         p = tmp_path / f"m{i:02d}.npy"
         np.save(p, a)
         paths.append(str(p)); arrays.append(a)
-    for depth in (0, 1, 3, 16):
+    # a Fortran-ordered file (numpy's general loader, not the piece-wise reader) and a map larger than several pieces
+    f = np.asfortranarray(rng.standard_normal((4, 6, 5)).astype(np.float32))
+    np.save(tmp_path / "m07.npy", f)
+    paths.append(str(tmp_path / "m07.npy")); arrays.append(np.ascontiguousarray(f))
+    big = rng.standard_normal((16, 96, 130)).astype(np.float16)
+    np.save(tmp_path / "m08.npy", big)
+    paths.append(str(tmp_path / "m08.npy")); arrays.append(big)
+    for depth, chunk, threads in ((0, None, None), (1, None, 1), (3, 4096, 3), (16, 100000, None), (2, 1 << 20, 2)):
+        feeder = FeatureFeeder(paths, DEV, depth, io_threads=threads)
+        if chunk:
+            feeder.CHUNK = chunk                 # small pieces: every file is cut into many, the last one short
         seen = []
-        for i, p, t in FeatureFeeder(paths, DEV, depth):
+        for i, p, t in feeder:
             assert p == paths[i] and t.is_cuda
             seen.append(t.cpu().numpy())
-        assert len(seen) == 7
+        assert len(seen) == len(paths)
         for a, b in zip(arrays, seen):
-            assert a.dtype == b.dtype and a.tobytes() == b.tobytes()
+            assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()

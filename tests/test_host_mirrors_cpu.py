@@ -139,3 +139,21 @@ def test_prepare_tensor_data_color_writes_the_reference_schema_with_image_key(tm
     ptdc.main(common + ["--images_dir", str(tmp_path / "nowhere")])
     d2 = torch.load(out, weights_only=False)
     assert d2["encoded_2d_features"].shape == (1, 1, 5, 7, 4) and d2["image"].shape == (5, 7, 3) and not d2["image"].any()
+
+
+def test_npy_layout_reads_the_header_only(tmp_path):
+    # the feeder's piece-wise reader needs (data offset, shape, dtype) of plain C-ordered arrays and must hand anything else
+    # (Fortran order, object arrays) to numpy's loader
+    import aggregate_voxel_features_onthefly as agg
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((5, 7, 9)).astype(np.float16)
+    np.save(tmp_path / "a.npy", a)
+    off, shape, dtype = agg._npy_layout(str(tmp_path / "a.npy"))
+    assert shape == (5, 7, 9) and dtype == np.float16
+    raw = open(tmp_path / "a.npy", "rb").read()
+    assert raw[off:] == a.tobytes() and len(raw) == off + a.nbytes
+    np.save(tmp_path / "f.npy", np.asfortranarray(a))
+    assert agg._npy_layout(str(tmp_path / "f.npy")) is None
+    np.save(tmp_path / "o.npy", np.array([{"k": 1}], dtype=object), allow_pickle=True)
+    assert agg._npy_layout(str(tmp_path / "o.npy")) is None
+    assert agg._granted_cpus() >= 1

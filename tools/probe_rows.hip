@@ -18,16 +18,32 @@ __device__ __forceinline__ unsigned long long mix(unsigned long long x)
     return x;
 }
 
+// store_mode: 0 = no store; 1 = every wavefront ends by writing one row to a RANDOM row of `dst` (what the gather does with
+// its finished output row); 2 = to the row of its own wave index (sequential, compact: a staging buffer); `dst_rows` rows.
+// Variants of mode 1: 3 = the store is issued HALF-WAY through the wavefront's reads instead of at its end; 4 = non-temporal
+// store; 5 = only the first 1 KiB of the row; 6 = two rows; 7 = the row is read first (read-modify-write, like the gather).
 template <int LOADS>   // 1-KiB wave-loads per row
 __global__ __launch_bounds__(256) void k_probe_rows(const float *__restrict__ src, long long first_row, long long window_rows,
-                                                    int iters, unsigned long long seed, float *sink)
+                                                    int iters, unsigned long long seed, float *sink,
+                                                    float *dst, long long dst_rows, int store_mode)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const unsigned long long wave = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     v4f acc = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
+    const long long rrow = (long long)(mix(seed ^ (wave * 0xD1B54A32D192ED03ull)) % (unsigned long long)(dst_rows > 0 ? dst_rows : 1));
+    if (store_mode == 7) {
+        const float *q = dst + rrow * (LOADS * 256) + lane * 4;
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) acc += *reinterpret_cast<const v4f *>(q + k * 256);
+    }
     for (int it = 0; it < iters; it += U) {
+        if (store_mode == 3 && it == ((iters / 2) & ~(U - 1))) {
+            float *q = dst + rrow * (LOADS * 256) + lane * 4;
+#pragma unroll
+            for (int k = 0; k < LOADS; k++) *reinterpret_cast<v4f *>(q + k * 256) = acc;
+        }
         v4f r[U][LOADS];
 #pragma unroll
         for (int j = 0; j < U; j++) {
@@ -42,17 +58,42 @@ __global__ __launch_bounds__(256) void k_probe_rows(const float *__restrict__ sr
 #pragma unroll
             for (int k = 0; k < LOADS; k++) acc += r[j][k];
     }
+    if (store_mode != 0 && store_mode != 3) {
+        const long long row = store_mode == 2 ? (long long)(wave % (unsigned long long)dst_rows) : rrow;
+        float *q = dst + row * (LOADS * 256) + lane * 4;
+        if (store_mode == 4) {
+#pragma unroll
+            for (int k = 0; k < LOADS; k++) __builtin_nontemporal_store(acc, reinterpret_cast<v4f *>(q + k * 256));
+        } else if (store_mode == 5) {
+            *reinterpret_cast<v4f *>(q) = acc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < LOADS; k++) *reinterpret_cast<v4f *>(q + k * 256) = acc;
+            if (store_mode == 6) {
+                float *q2 = dst + ((rrow + dst_rows / 2) % dst_rows) * (LOADS * 256) + lane * 4;
+#pragma unroll
+                for (int k = 0; k < LOADS; k++) *reinterpret_cast<v4f *>(q2 + k * 256) = acc;
+            }
+        }
+    }
     if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;   // keeps the loads alive
 }
 
 }  // namespace
 
+extern "C" int probe_rows_store(const float *src, long long first_row, long long window_rows, int row_bytes, int waves, int iters,
+                                unsigned long long seed, float *sink, float *dst, long long dst_rows, int store_mode, void *stream)
+{
+    if (!src || !sink || window_rows <= 0 || waves <= 0 || iters <= 0 || (row_bytes != 1024 && row_bytes != 2048)) return 1;
+    if (store_mode != 0 && (!dst || dst_rows <= 0)) return 1;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (row_bytes == 2048) hipLaunchKernelGGL(k_probe_rows<2>, grid, dim3(256), 0, (hipStream_t)stream, src, first_row, window_rows, iters, seed, sink, dst, dst_rows, store_mode);
+    else hipLaunchKernelGGL(k_probe_rows<1>, grid, dim3(256), 0, (hipStream_t)stream, src, first_row, window_rows, iters, seed, sink, dst, dst_rows, store_mode);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 extern "C" int probe_rows(const float *src, long long first_row, long long window_rows, int row_bytes, int waves, int iters,
                           unsigned long long seed, float *sink, void *stream)
 {
-    if (!src || !sink || window_rows <= 0 || waves <= 0 || iters <= 0 || (row_bytes != 1024 && row_bytes != 2048)) return 1;
-    const dim3 grid((unsigned)((waves + 3) / 4));
-    if (row_bytes == 2048) hipLaunchKernelGGL(k_probe_rows<2>, grid, dim3(256), 0, (hipStream_t)stream, src, first_row, window_rows, iters, seed, sink);
-    else hipLaunchKernelGGL(k_probe_rows<1>, grid, dim3(256), 0, (hipStream_t)stream, src, first_row, window_rows, iters, seed, sink);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    return probe_rows_store(src, first_row, window_rows, row_bytes, waves, iters, seed, sink, nullptr, 0, 0, stream);
 }
