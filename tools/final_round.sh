@@ -1,0 +1,22 @@
+#!/bin/bash
+# Everything profiles/ needs for a round, on the GPU box from the repo root: bash tools/final_round.sh r03
+# (GPU tests, rocprofv3 kernel trace + PMC traffic passes, every bench leg, the auxiliary benches).  Afterwards, in the build
+# container: bash tools/collect_profiles.sh r03
+set -o pipefail
+tag=${1:-r03}
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+echo "[final] gpu tests $(date +%T)"
+timeout -k 10 900 python3 -m pytest tests -m gpu -q > gpurun_out/${tag}_gputest.log 2>&1; echo "[final] pytest rc $?"; tail -n 3 gpurun_out/${tag}_gputest.log
+echo "[final] benches $(date +%T)"
+timeout -k 10 1200 bash tools/run_benches.sh $tag || echo "[final] run_benches failed"
+echo "[final] profile round $(date +%T)"
+timeout -k 10 1500 bash tools/profile_round.sh $tag || echo "[final] profile_round failed"
+echo "[final] auxiliary $(date +%T)"
+timeout -k 10 300 python3 tools/bench_prep.py > gpurun_out/${tag}_bench_prep.log 2>&1
+timeout -k 10 300 python3 tools/bench_dropin.py > gpurun_out/${tag}_bench_dropin.log 2>&1
+timeout -k 10 300 python3 tools/bench_stage5.py > gpurun_out/${tag}_bench_stage5.log 2>&1
+timeout -k 10 300 python3 tools/bench_entry_files.py 24 > gpurun_out/${tag}_bench_entry_files.log 2>&1
+for f in gpurun_out/${tag}_bench_*.log; do echo "== $f"; grep '^{' $f | tail -1 | cut -c1-600; done
+echo "[final] done $(date +%T)"
