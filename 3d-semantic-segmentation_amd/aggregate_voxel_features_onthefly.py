@@ -31,13 +31,15 @@ import argparse
 import glob
 import os
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL over dmabuf IPC on this pool's hosts (multi-GPU --mode fast)
 
-import build_sparse_occupancy as bso
-import prepare_tensor_data as ptd
-import voxproj_host
-from debug_project_features import build_id_to_zyx
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import build_sparse_occupancy as bso  # noqa: E402
+import prepare_tensor_data as ptd  # noqa: E402
+import voxproj_host  # noqa: E402
+from debug_project_features import build_id_to_zyx  # noqa: E402
 
 CHECKPOINT_DIR = "voxel_feature_checkpoints"
 LSEG_DIR = "lseg_embed_features/features"

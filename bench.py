@@ -27,6 +27,10 @@ import os
 import sys
 import time
 
+# the pool's host driver only supports dmabuf IPC: without this RCCL fails with "hipIpcGetMemHandle: invalid argument"
+# (already exported on the GPU boxes; set here too so that a bare torchrun of this file works)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "3d-semantic-segmentation_amd")
 for _p in (ROOT, PKG):

@@ -16,6 +16,6 @@ grep '^{' gpurun_out/prof_$tag/bench_under_rocprof.log | tail -1 > $P/${tag}_ben
   echo "#   rocprofv3 --pmc FETCH_SIZE -d <out>/fetch_<dt> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 120 --chunk 60 [--dtype f16]"
   echo "#   rocprofv3 --pmc WRITE_SIZE -d <out>/write_<dt> -- (same)      (separate passes; counter passes serialise kernels: their durations are not the bench's)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_R4  -- python3 bench.py --workload R4 --no-cpu-baseline"
-  echo "# k_gather averages over ALL launches of a process (placement pass 20, pre-pass 10, warm-up 10, timed 30, after-pass 20 = 90);"
+  echo "# k_gather averages over ALL launches of a process (placement pass 10, pre-pass 5, warm-up 5, timed 15, after-pass 10 = 45 at 5 calls of 60 views per pass);"
   echo "# FETCH_SIZE is in KB and counts 64 B per 128-B request for 16-B-per-lane streaming reads on gfx950 -> doubled in profiles/${tag}_pmc_traffic.json's reader"
   cat gpurun_out/prof_$tag/summary.txt | cut -c1-420; } > $P/${tag}_rocprofv3_summary.txt
