@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--heavy-threshold", type=int, default=0,
                     help="experiment: VP_OPT_HEAVY_THRESHOLD of the workspace (pixels per voxel and call above which a whole "
                          "workgroup sums the voxel); 0 = the library's default, 256 + 64 x views per call")
+    ap.add_argument("--march-lds-kb", type=int, default=-1,
+                    help="experiment: VP_OPT_MARCH_LDS_KB of the workspace (dynamic-LDS reservation of the march = its occupancy "
+                         "cap beside a gather); -1 = the library's default (41 KiB = 3 workgroups per CU)")
     ap.add_argument("--no-overlap-reduce", action="store_true",
                     help="multi-GPU: skip the extra, overlapped measurement (the collective of pass k on RCCL's stream while "
                          "pass k+1 is projected into a second buffer; reported under 'overlapped_passes').  The headline "
@@ -469,6 +472,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.dist_backend)
+        # communicator set-up is lazy: pay it here, not in the first timed step (the driver may pass --warmup 0)
+        _t = torch.zeros(1, device=dev)
+        dist.all_reduce(_t)
+        torch.cuda.synchronize(dev)
 
     import voxproj_host
     from synthetic_scene import make_features_torch, make_scene
@@ -526,6 +533,8 @@ def main():
     ws = voxproj_host.Workspace()
     if a.heavy_threshold > 0:
         ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, a.heavy_threshold)
+    if a.march_lds_kb >= 0:
+        ws.set_option(voxproj_host.VP_OPT_MARCH_LDS_KB, a.march_lds_kb)
 
     # calls of one step: (pool slot of the first view, view indices)
     calls = []
@@ -645,6 +654,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if dist is not None:
+        # one untimed collective at the real size (RCCL sizes its channels and staging on first use), whatever --warmup says
+        scratch = [torch.zeros_like(out), torch.zeros_like(count)]
+        reduce_partials(dist, scratch, dst=dst)
+        torch.cuda.synchronize(dev)
+        del scratch
     for _ in range(a.warmup):
         step()
     barrier()
