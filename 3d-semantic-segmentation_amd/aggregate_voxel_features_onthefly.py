@@ -278,9 +278,18 @@ def _npy_layout(path):
         if read is None:
             return None
         shape, fortran, dtype = read(f)
-        if fortran or dtype.hasobject:
+        # plain native-endian numbers only: the bytes go to the device as they are and are viewed as the torch dtype of the same name
+        if fortran or dtype.hasobject or dtype.fields is not None or not dtype.isnative or not isinstance(getattr(torch, dtype.name, None), torch.dtype):
             return None
         return f.tell(), tuple(int(v) for v in shape), dtype
+
+
+def _load_native(path):
+    """numpy's loader, C-ordered and in native byte order (what torch.from_numpy accepts)."""
+    a = np.load(path)
+    if not a.dtype.isnative:
+        a = a.astype(a.dtype.newbyteorder("="))
+    return np.ascontiguousarray(a)
 
 
 class FeatureFeeder:
@@ -309,7 +318,7 @@ class FeatureFeeder:
     def __iter__(self):
         if self.depth <= 0:
             for i, p in enumerate(self.paths):
-                yield i, p, torch.from_numpy(np.ascontiguousarray(np.load(p))).to(self.dev)
+                yield i, p, torch.from_numpy(_load_native(p)).to(self.dev)
             return
         from concurrent.futures import ThreadPoolExecutor
         nbuf = self.depth + 2
@@ -333,7 +342,7 @@ class FeatureFeeder:
                 copied[b].synchronize()                          # view i - nbuf has left this buffer
                 copied[b] = None
             if lay is None:
-                return None, b, None, [pool.submit(lambda p=self.paths[i]: np.ascontiguousarray(np.load(p)))]
+                return None, b, None, [pool.submit(_load_native, self.paths[i])]
             off0, shape, dtype = lay
             nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
             if pinned[b] is None or pinned[b].numel() < nbytes:

@@ -574,6 +574,9 @@ def test_feature_feeder_delivers_every_map_in_order(tmp_path):
     f = np.asfortranarray(rng.standard_normal((4, 6, 5)).astype(np.float32))
     np.save(tmp_path / "m07.npy", f)
     paths.append(str(tmp_path / "m07.npy")); arrays.append(np.ascontiguousarray(f))
+    be = rng.standard_normal((3, 5, 4)).astype(">f4")                    # foreign byte order: converted by the general loader
+    np.save(tmp_path / "m07b.npy", be)
+    paths.append(str(tmp_path / "m07b.npy")); arrays.append(be.astype("<f4"))
     big = rng.standard_normal((16, 96, 130)).astype(np.float16)
     np.save(tmp_path / "m08.npy", big)
     paths.append(str(tmp_path / "m08.npy")); arrays.append(big)

@@ -156,4 +156,8 @@ def test_npy_layout_reads_the_header_only(tmp_path):
     assert agg._npy_layout(str(tmp_path / "f.npy")) is None
     np.save(tmp_path / "o.npy", np.array([{"k": 1}], dtype=object), allow_pickle=True)
     assert agg._npy_layout(str(tmp_path / "o.npy")) is None
+    np.save(tmp_path / "be.npy", a.astype(">f4"))                       # foreign byte order: numpy's loader converts, the piece reader must not
+    assert agg._npy_layout(str(tmp_path / "be.npy")) is None
+    np.save(tmp_path / "s.npy", np.zeros(3, dtype=[("x", "f4"), ("y", "i2")]))
+    assert agg._npy_layout(str(tmp_path / "s.npy")) is None
     assert agg._granted_cpus() >= 1
