@@ -65,13 +65,14 @@
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
-// the same for k_gather, whose fourth template argument says whether the launch carries the heavy-voxel role
-#define VP_DISPATCH_GATHER(MERGED, VEC_OK, C, ...)                                \
+// the same for k_gather, whose fourth template argument says whether the launch carries the heavy-voxel role and whose
+// fifth is the number of views whose first ID tile is fetched together (G32: 1 or 4 for fp32 rows, vp_gather.h)
+#define VP_DISPATCH_GATHER(MERGED, G32, VEC_OK, C, ...)                           \
     do {                                                                          \
-        if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather<1, 8, VP_F16_U, MERGED>), __VA_ARGS__);    \
-        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather<2, 4, 4, MERGED>), __VA_ARGS__); \
-        else if (VEC_OK) hipLaunchKernelGGL((k_gather<1, 4, 4, MERGED>), __VA_ARGS__);      \
-        else hipLaunchKernelGGL((k_gather<4, 1, 4, MERGED>), __VA_ARGS__);                  \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather<1, 8, VP_F16_U, MERGED, GATHER_G16>), __VA_ARGS__);    \
+        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather<2, 4, 4, MERGED, G32>), __VA_ARGS__); \
+        else if (VEC_OK) hipLaunchKernelGGL((k_gather<1, 4, 4, MERGED, G32>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((k_gather<4, 1, 4, MERGED, 1>), __VA_ARGS__);               \
     } while (0)
 
 // rows in flight per wavefront in the fp16 gather
@@ -295,6 +296,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // Heavy voxels: the first workgroups of the gather's own launch when the call has many views; a launch of their own
     // in front of it, 16 wavefronts per voxel, when it has few (vp_gather.h)
     const bool merged_heavy = (long long)B * V >= 8;
+    const bool small_image = (long long)H * W <= GATHER_G32_SMALL_IMAGE;
     g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
     if (pipe) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
     if (!merged_heavy) {
@@ -306,8 +308,10 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         ProfSpan sp; sp.begin(2, s0);
         const dim3 ggrid(g.heavy_blocks + (blocks_n > 0 ? blocks_n : 0));
         if (ggrid.x == 0) { /* n_rows == 1: only the dummy row 0, nothing to gather */ }
-        else if (merged_heavy) VP_DISPATCH_GATHER(true, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
-        else VP_DISPATCH_GATHER(false, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+        else if (merged_heavy && small_image) VP_DISPATCH_GATHER(true, 4, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+        else if (merged_heavy) VP_DISPATCH_GATHER(true, 1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+        else if (small_image) VP_DISPATCH_GATHER(false, 4, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+        else VP_DISPATCH_GATHER(false, 1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         sp.end();
     }
     if (pipe) {

@@ -232,14 +232,12 @@ constexpr int GW_MERGED = 4;     // wavefronts that share one heavy voxel inside
 constexpr int GW_ALONE = 16;     // ... in k_gather_heavy, the separate launch used for calls of few views
 constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather that take the heavy voxels
 
-// views whose first ID tile is fetched together by the one-wavefront gather (1 = one view at a time)
-#ifndef VP_GATHER_G16
-#define VP_GATHER_G16 4
-#endif
-#ifndef VP_GATHER_G32
-#define VP_GATHER_G32 1
-#endif
-#define VP_GATHER_G(VEC) ((VEC) == 8 ? VP_GATHER_G16 : VP_GATHER_G32)
+// Views whose first ID tile is fetched together by the one-wavefront gather (template argument G of k_gather; 1 = one view
+// at a time).  fp16 rows: 4 (-1 % pipelined, round 2).  fp32 rows: 4 for small images (a voxel of R1's 484x274 views gathers
+// half the rows per view an R2 voxel does, so the dependent tile fetch in front of them weighs twice as much: -1.4 % per
+// pipelined R1 call), 1 otherwise (968x548: equal alone, +0.3 % pipelined) -- profiles/r03_ab_id_tile_grouping_fp32.log.
+constexpr int GATHER_G16 = 4;
+constexpr long long GATHER_G32_SMALL_IMAGE = 262144;     // pixels per view up to which fp32 calls use G = 4
 
 // Output rows are read once and written once per call by the wavefront that owns the voxel: no reuse inside a launch.
 // VP_OUT_NT = 1 makes both accesses non-temporal, like the feature rows (A/B: tools/probe_levels_rr.py).
@@ -595,7 +593,7 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
 // -0.4 % fp32; serial phases -1.0 .. -1.4 %).
 // MERGED = false: without that role the kernel needs 96 VGPRs = 5 wavefronts per SIMD, worth 5 % on a one-view call
 // (0.372 vs 0.392 ms per blocking R2 call); the heavy voxels of such calls go to k_gather_heavy below.
-template <int K, int VEC, int U, bool MERGED>
+template <int K, int VEC, int U, bool MERGED, int G>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
     // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
@@ -633,7 +631,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     }
     if (id == 0) return;
     const int expected = g.cnt_call[id];
-    gather_voxel_wave<K, VEC, U, VP_GATHER_G(VEC)>(g, p, id, expected, lane);
+    gather_voxel_wave<K, VEC, U, G>(g, p, id, expected, lane);
 }
 
 // Calls of few views (the drop-in module's one view per call): the heavy voxels are few, each a large share of a short

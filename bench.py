@@ -60,8 +60,9 @@ def parse():
     ap.add_argument("--entry", default=None, choices=("parity", "fast"),
                     help="time the named entry point's in-process aggregation (VoxelFeatureAggregator.add_views over every "
                          "view of the workload, features resident) instead of raw C-ABI calls; default workload R1")
-    ap.add_argument("--entry-pipeline", action="store_true",
-                    help="--entry parity: A/B arm, run the one-view calls in the pipelined job mode (VP_FLAG_PIPELINE)")
+    ap.add_argument("--entry-no-pipeline", action="store_true",
+                    help="--entry parity: A/B arm, plain asynchronous one-view calls instead of the aggregator's default, the "
+                         "pipelined job mode (VP_FLAG_PIPELINE)")
     ap.add_argument("--collective", default="allreduce", choices=("reduce", "allreduce"),
                     help="multi-GPU: how the per-rank {sum,count} are combined each pass.  allreduce (default) = the single RCCL "
                          "all-reduce north_star names, every rank gets the scene; reduce = to rank 0 only, half the xGMI "
@@ -354,7 +355,7 @@ def bench_entry(a, dev, rank, world, dist):
     c2w = torch.from_numpy(s.c2w).to(dev)
     intr4 = torch.from_numpy(s.intr)
     agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, C, a.entry, dev,
-                                 parity_pipeline=a.entry_pipeline)
+                                 parity_pipeline=not a.entry_no_pipeline)
     per_call = 1 if a.entry == "parity" else max(1, min(8, a.chunk or 8))
     calls = [my_views[i:i + per_call] for i in range(0, len(my_views), per_call)]
     # the poses of every call, on the device and READY before the first call (a pipelined call's side stream reads them

@@ -6,8 +6,9 @@ o=gpurun_out
 python3 bench.py > $o/${tag}_bench_default.log 2>&1 || exit 1
 python3 bench.py --dtype f16 --no-cpu-baseline > $o/${tag}_bench_f16.log 2>&1 || exit 1
 python3 bench.py --workload R1 --no-cpu-baseline > $o/${tag}_bench_R1.log 2>&1 || exit 1
+python3 bench.py --workload R1 --min-calls 1 --chunk 100 --no-cpu-baseline > $o/${tag}_bench_R1_one_call.log 2>&1 || exit 1
 python3 bench.py --workload R4 > $o/${tag}_bench_R4.log 2>&1 || exit 1
 python3 bench.py --entry parity --no-cpu-baseline > $o/${tag}_bench_entry_parity.log 2>&1 || exit 1
-python3 bench.py --entry parity --entry-pipeline --no-cpu-baseline > $o/${tag}_bench_entry_parity_pipelined.log 2>&1 || exit 1
+python3 bench.py --entry parity --entry-no-pipeline --no-cpu-baseline > $o/${tag}_bench_entry_parity_unpipelined.log 2>&1 || exit 1
 python3 bench.py --entry fast --no-cpu-baseline > $o/${tag}_bench_entry_fast.log 2>&1 || exit 1
 python3 bench.py --no-pipeline --no-cpu-baseline > $o/${tag}_bench_serial.log 2>&1 || exit 1
