@@ -232,6 +232,13 @@ def cpu_torch_loop(scene, n_views, n_threads):
                 sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {inb} centres in bounds")
 
 
+def device_info(dev):
+    """Which GPU a line was measured on: the speed level of a run follows the box as much as the allocation."""
+    p = torch.cuda.get_device_properties(dev)
+    return {"name": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+            "uuid": str(getattr(p, "uuid", "")) or None, "hbm_gb": round(p.total_memory / 1e9, 1)}
+
+
 def _barrier(dist, dev):
     if dist is not None:
         dist.barrier()
@@ -762,7 +769,7 @@ def main():
                                   "gather": round(prof["gather_ms"] / a.steps, 3),
                                   "gather_heavy": round(prof["heavy_ms"] / a.steps, 3),
                                   "overlapped": pipeline},
-            "pool_placement": placement, **reduced,
+            "pool_placement": placement, "device": device_info(dev), **reduced,
             **({"collective": {"op": "reduce to rank 0" if a.collective == "reduce" else "all-reduce", "backend": a.dist_backend,
                                "bytes_per_rank": n_rows * C * 4 + n_rows * 4,
                                "collective_ms_exposed": round(exposed_ms, 3),
