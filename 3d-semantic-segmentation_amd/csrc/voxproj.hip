@@ -271,7 +271,12 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
                 beside_gather = hipEventQuery(ps->call_done[q ^ 1]) == hipErrorNotReady;
                 (void)hipGetLastError();   // hipErrorNotReady is an answer, not a failure
             }
-            size_t lds_req = beside_gather ? 41 * 1024 : 0;
+            // Rows of up to 1 KiB (fp16 maps of 512 channels, fp32 maps of 256): the gather moves half the bytes per view, so a
+            // march held to 3 workgroups per CU takes longer than the gather it hides under and becomes the critical path
+            // (30.1 vs 29.2 ms per fp16 pass); 5 workgroups per CU (30 KiB) bring the pass from 33.1-33.7 to 29.5-31.6 ms,
+            // 6 and 4 are worse (profiles/r03_march_occupancy_cap_sweep.log).
+            const size_t row_bytes = size_t(C) * (feats_f16 ? 2 : 4);
+            size_t lds_req = beside_gather ? (row_bytes <= 1024 ? 30 : 41) * 1024 : 0;
             if (rec.opt_march_lds_kb >= 0) lds_req = size_t(std::min<long long>(rec.opt_march_lds_kb, 160)) * 1024;   // VP_OPT_MARCH_LDS_KB
             hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
