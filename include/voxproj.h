@@ -275,8 +275,9 @@ int vp_workspace_release(void *workspace);
  * library reads no environment variable).  value < 0 (or 0 for the threshold) restores the default.
  *   VP_OPT_HEAVY_THRESHOLD  voxels that collect more than this many pixels in ONE call are summed by a whole workgroup
  *                           (default 256 + 64*B*V; VP_FLAG_SERIAL_SUMS overrides it with "never")
- *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default: 41 KiB
- *                           beside a running gather in VP_FLAG_PIPELINE mode, 0 otherwise)
+ *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
+ *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a
+ *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise)
  */
 enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2 };
 int vp_workspace_set_option(void *workspace, int option, long long value);
