@@ -301,7 +301,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // Heavy voxels: the first workgroups of the gather's own launch when the call has many views; a launch of their own
     // in front of it, 16 wavefronts per voxel, when it has few (vp_gather.h)
     const bool merged_heavy = (long long)B * V >= 8;
-    const bool small_image = (long long)H * W <= GATHER_G32_SMALL_IMAGE;
+    const bool small_image = merged_heavy && (long long)H * W <= GATHER_G32_SMALL_IMAGE;   // grouping needs views to group
     g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
     if (pipe) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
     if (!merged_heavy) {
@@ -315,7 +315,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         if (ggrid.x == 0) { /* n_rows == 1: only the dummy row 0, nothing to gather */ }
         else if (merged_heavy && small_image) VP_DISPATCH_GATHER(true, 4, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         else if (merged_heavy) VP_DISPATCH_GATHER(true, 1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
-        else if (small_image) VP_DISPATCH_GATHER(false, 4, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         else VP_DISPATCH_GATHER(false, 1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
         sp.end();
     }

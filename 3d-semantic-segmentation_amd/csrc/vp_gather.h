@@ -240,29 +240,33 @@ constexpr int GATHER_G16 = 4;
 constexpr long long GATHER_G32_SMALL_IMAGE = 262144;     // pixels per view up to which fp32 calls use G = 4
 
 // Output rows are read once and written once per call by the wavefront that owns the voxel: no reuse inside a launch.
-// VP_OUT_NT = 1 makes both accesses non-temporal, like the feature rows (A/B: tools/probe_levels_rr.py).
-#ifndef VP_OUT_NT
-#define VP_OUT_NT 0
-#endif
+// The finished row is stored WRITE-THROUGH (buffer_store_dwordx4 with the sc0 sc1 cache-policy bits): stores that leave
+// dirty lines in L2 cost this read-bound kernel far more than their bytes, and on some (feature pool, output rows)
+// placement pairs several times more (tools/probe_stores.py: +3.9 % per launch for one plain 2-KiB store per 272 rows
+// read, +12.7 % on a bad pair; +2.3 % / +4.6 % written through; the same through uncached memory or a non-temporal store).
+// In the gather itself: -0.3 ... -1.5 % per launch (profiles/r03_ab_output_row_store_policy.log).  The row's load stays a
+// plain load (a non-temporal load of the row was measured slower).  Visibility is that of a plain store: the line goes
+// to memory at system scope and the next kernel reads it from there.
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+constexpr int OUT_ST_POLICY = 0x11;     // aux bits of the raw buffer store on gfx940+: sc0 (bit 0) | sc1 (bit 4)
+
 __device__ __forceinline__ float4 ld_out4(const float *p)
 {
-#if VP_OUT_NT
-    typedef float v4f_ __attribute__((ext_vector_type(4)));
-    const v4f_ t = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
-#else
     return *reinterpret_cast<const float4 *>(p);
-#endif
 }
-__device__ __forceinline__ void st_out4(float *p, float4 v)
+
+// store 16 bytes at row + byte_off, row wave-uniform (one buffer descriptor per row chunk: base = the row, no bound)
+__device__ __forceinline__ void st_out4(__amdgpu_buffer_rsrc_t row, int byte_off, float4 v)
 {
-#if VP_OUT_NT
     typedef float v4f_ __attribute__((ext_vector_type(4)));
-    v4f_ t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<v4f_ *>(p));
-#else
-    *reinterpret_cast<float4 *>(p) = v;
-#endif
+    const v4f_ t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_, t), row, byte_off, 0, OUT_ST_POLICY);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_row_rsrc(float *orow)
+{
+    // raw buffer, stride 0, num_records = 2^31 bytes (the callers bound their accesses themselves), gfx9 dword 3 for 32-bit data
+    return __builtin_amdgcn_make_buffer_rsrc(orow, 0, 0x7fffffff, 0x00020000);
 }
 
 template <int K, int VEC>
@@ -288,9 +292,33 @@ __device__ __forceinline__ void acc_load(Acc<K, VEC> &acc, const float *orow, in
     }
 }
 
-template <int K, int VEC>
+// WT: write-through stores (the multi-view launches); false: plain stores -- the one-view-per-call variant of k_gather stays
+// at 96 VGPRs = 5 wavefronts per SIMD that way (the buffer form costs 5 registers), which is worth more to a 0.25-ms launch.
+template <int K, int VEC, bool WT>
 __device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, int cb, int C, int lane)
 {
+    if constexpr (!WT) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if constexpr (VEC == 8) {
+                const int ch = (k * 64 + lane) * 8;
+                if (cb + ch < C) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+                        *reinterpret_cast<float4 *>(orow + ch + h * 4) = make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+                }
+            } else if constexpr (VEC == 4) {
+                const int ch = (k * 64 + lane) * 4;
+                if (cb + ch < C)
+                    *reinterpret_cast<float4 *>(orow + ch) = make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+            } else {
+                const int ch = k * 64 + lane;
+                if (cb + ch < C) orow[ch] = acc.a[k];
+            }
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t row = out_row_rsrc(orow);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         if constexpr (VEC == 8) {
@@ -298,12 +326,12 @@ __device__ __forceinline__ void acc_store(const Acc<K, VEC> &acc, float *orow, i
             if (cb + ch < C) {
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    st_out4(orow + ch + h * 4, make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]));
+                    st_out4(row, (ch + h * 4) * 4, make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]));
             }
         } else if constexpr (VEC == 4) {
             const int ch = (k * 64 + lane) * 4;
             if (cb + ch < C)
-                st_out4(orow + ch, make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]));
+                st_out4(row, ch * 4, make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]));
         } else {
             const int ch = k * 64 + lane;
             if (cb + ch < C) orow[ch] = acc.a[k];
@@ -340,7 +368,7 @@ __device__ __forceinline__ float near_plane(const Params &p)
 
 // Normal role: one wavefront sums all pixels of one voxel, in (b, v, y, x) order, starting from the
 // row already in `out` -- bit-identical to the oracle's serial accumulation.
-template <int K, int VEC, int U, int G>
+template <int K, int VEC, int U, int G, bool WT>
 __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Params &p, int id, int expected, int lane)
 {
     const int W = p.width, H = p.height, C = p.C;
@@ -432,7 +460,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
 #if defined(VP_DIAG_NOSTORE)
         if (found == -12345)        // timing experiment only: never true, keeps the sums alive -- outputs are NOT written
 #endif
-        acc_store<K, VEC>(acc, orow, cb, C, lane);
+        acc_store<K, VEC, WT>(acc, orow, cb, C, lane);
         if (cb == 0 && lane == 0) {
             g.count[id] += found;   // K.cu:77 (one add of the per-call total)
             if (g.views_hit) g.views_hit[id] += nviews;
@@ -631,7 +659,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     }
     if (id == 0) return;
     const int expected = g.cnt_call[id];
-    gather_voxel_wave<K, VEC, U, G>(g, p, id, expected, lane);
+    gather_voxel_wave<K, VEC, U, G, MERGED>(g, p, id, expected, lane);
 }
 
 // Calls of few views (the drop-in module's one view per call): the heavy voxels are few, each a large share of a short

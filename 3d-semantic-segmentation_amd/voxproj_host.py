@@ -514,7 +514,7 @@ class _ContiguousDeviceMemory:
 
     _hip = None
 
-    def __init__(self, nbytes, shape, typestr):
+    def __init__(self, nbytes, shape, typestr, flags=0x4):
         cls = _ContiguousDeviceMemory
         if cls._hip is None:
             cls._hip = ctypes.CDLL("libamdhip64.so")
@@ -522,9 +522,10 @@ class _ContiguousDeviceMemory:
             cls._hip.hipExtMallocWithFlags.restype = ctypes.c_int
             cls._hip.hipFree.argtypes = [ctypes.c_void_p]
         p = ctypes.c_void_p()
-        rc = cls._hip.hipExtMallocWithFlags(ctypes.byref(p), max(int(nbytes), 256), 0x4)      # hipDeviceMallocContiguous
+        # 0x4 hipDeviceMallocContiguous (default); experiments also use 0x1 hipDeviceMallocFinegrained, 0x3 hipDeviceMallocUncached
+        rc = cls._hip.hipExtMallocWithFlags(ctypes.byref(p), max(int(nbytes), 256), int(flags))
         if rc != 0 or not p.value:
-            raise MemoryError(f"hipExtMallocWithFlags(hipDeviceMallocContiguous, {nbytes} bytes) failed: hip error {rc}")
+            raise MemoryError(f"hipExtMallocWithFlags(flags {flags:#x}, {nbytes} bytes) failed: hip error {rc}")
         self.ptr = p.value
         self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (self.ptr, False),
                                          "version": 2}
@@ -538,7 +539,7 @@ class _ContiguousDeviceMemory:
             pass
 
 
-def resident_empty(shape, dtype, device, fallback=True):
+def resident_empty(shape, dtype, device, fallback=True, flags=0x4):
     """An uninitialised CUDA tensor for a long-lived, heavily gathered buffer (the resident feature maps, the output rows)
     in PHYSICALLY CONTIGUOUS device memory (hipExtMallocWithFlags, hipDeviceMallocContiguous).  An experiment on the
     placement spread of DESIGN.md section 4 (tools/probe_contig.py): inside one process a 17 GB pool re-allocated this way
@@ -554,7 +555,7 @@ def resident_empty(shape, dtype, device, fallback=True):
         n *= int(v)
     try:
         with torch.cuda.device(dev):
-            mem = _ContiguousDeviceMemory(n * torch.empty((), dtype=dtype).element_size(), shape, typestr)
+            mem = _ContiguousDeviceMemory(n * torch.empty((), dtype=dtype).element_size(), shape, typestr, flags)
             return torch.as_tensor(mem, device=dev), "contiguous"
     except (MemoryError, OSError):
         if not fallback:

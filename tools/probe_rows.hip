@@ -21,7 +21,8 @@ __device__ __forceinline__ unsigned long long mix(unsigned long long x)
 // store_mode: 0 = no store; 1 = every wavefront ends by writing one row to a RANDOM row of `dst` (what the gather does with
 // its finished output row); 2 = to the row of its own wave index (sequential, compact: a staging buffer); `dst_rows` rows.
 // Variants of mode 1: 3 = the store is issued HALF-WAY through the wavefront's reads instead of at its end; 4 = non-temporal
-// store; 5 = only the first 1 KiB of the row; 6 = two rows; 7 = the row is read first (read-modify-write, like the gather).
+// store; 5 = only the first 1 KiB of the row; 6 = two rows; 7 = the row is read first (read-modify-write, like the gather);
+// 8 / 9 / 10 = the store carries the cache-policy bits sc1 / sc0 sc1 / sc0 sc1 nt (write-through past L2, inline assembly).
 template <int LOADS>   // 1-KiB wave-loads per row
 __global__ __launch_bounds__(256) void k_probe_rows(const float *__restrict__ src, long long first_row, long long window_rows,
                                                     int iters, unsigned long long seed, float *sink,
@@ -64,6 +65,14 @@ __global__ __launch_bounds__(256) void k_probe_rows(const float *__restrict__ sr
         if (store_mode == 4) {
 #pragma unroll
             for (int k = 0; k < LOADS; k++) __builtin_nontemporal_store(acc, reinterpret_cast<v4f *>(q + k * 256));
+        } else if (store_mode >= 8 && store_mode <= 10) {
+#pragma unroll
+            for (int k = 0; k < LOADS; k++) {
+                float *a = q + k * 256;
+                if (store_mode == 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a), "v"(acc) : "memory");
+                else if (store_mode == 9) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a), "v"(acc) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(a), "v"(acc) : "memory");
+            }
         } else if (store_mode == 5) {
             *reinterpret_cast<v4f *>(q) = acc;
         } else {

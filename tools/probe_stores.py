@@ -18,6 +18,8 @@ import torch  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--allocs", type=int, default=4)
 ap.add_argument("--dsts", type=int, default=3)
+ap.add_argument("--dst-flags", default="", help="comma list of hipExtMallocWithFlags flags for extra destination buffers "
+                "(1 = fine-grained, 3 = uncached): is the store cost a property of the memory type?")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 L = ctypes.CDLL(os.path.join(ROOT, "tools", "libprobe_rows.so"))
@@ -29,6 +31,14 @@ pools = [torch.empty(ROWS * 512, dtype=torch.float32, device=dev).normal_() for 
 for _ in range(1, a.allocs):
     p = torch.empty_like(pools[0]); p.copy_(pools[0]); pools.append(p)
 dsts = [torch.zeros(200001 * 512, dtype=torch.float32, device=dev) for _ in range(a.dsts)]
+if a.dst_flags:
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-semantic-segmentation_amd")]
+    import voxproj_host
+    for fl in a.dst_flags.split(","):
+        t, kind = voxproj_host.resident_empty((200001 * 512,), torch.float32, dev, fallback=False, flags=int(fl))
+        t.zero_()
+        dsts.append(t)
+        print(f"destination buffer {len(dsts) - 1}: hipExtMallocWithFlags flags {fl}")
 sink = torch.zeros(4, device=dev)
 stream = torch.cuda.current_stream(dev).cuda_stream
 WAVES, ITERS = 63000, 272
@@ -54,5 +64,6 @@ for k, pool in enumerate(pools):
     rnd = [run(pool, d, 1) for d in dsts]
     seq = [run(pool, d, 2) for d in dsts]
     print(f"pool {k}: no store {base:.3f} | random-row store " + " ".join(f"{t:.3f}" for t in rnd) + " | own-slot store " + " ".join(f"{t:.3f}" for t in seq), flush=True)
-    names = {3: "store half-way", 4: "non-temporal store", 5: "1 KiB only", 6: "two rows", 7: "row read first (RMW)"}
+    names = {3: "store half-way", 4: "non-temporal store", 5: "1 KiB only", 6: "two rows", 7: "row read first (RMW)",
+             8: "sc1", 9: "sc0 sc1", 10: "sc0 sc1 nt"}
     print("         " + " | ".join(f"{names[m]} {run(pool, dsts[0], m):.3f}" for m in sorted(names)), flush=True)
