@@ -47,6 +47,7 @@ int main()
     HIP_OK(hipMalloc(&d_count, n_rows * sizeof(int32_t)));
     HIP_OK(hipMalloc(&d_out, n_rows * C * sizeof(float)));
     HIP_OK(hipMalloc(&d_ws, ws_bytes));                                    // hipMalloc is 256-byte aligned
+    if (vp_workspace_create(d_ws, ws_bytes) != VP_OK) { fprintf(stderr, "vp_workspace_create: %s\n", vp_last_error()); return 1; }
     HIP_OK(hipMemcpy(d_feats, feats.data(), feats.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_occ, occ.data(), occ.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_vmi, c2w, sizeof(c2w), hipMemcpyHostToDevice));
