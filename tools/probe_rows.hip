@@ -88,7 +88,48 @@ __global__ __launch_bounds__(256) void k_probe_rows(const float *__restrict__ sr
     if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;   // keeps the loads alive
 }
 
+// The same random whole-row read through raw buffer loads with a compile-time cache policy (aux bits on gfx940+: sc0 = 1,
+// nt = 2, sc1 = 16): does any policy stream rows faster than the plain non-temporal global load the gather uses?
+template <int AUX>
+__global__ __launch_bounds__(256) void k_probe_rows_policy(const float *__restrict__ src, long long window_rows, int iters,
+                                                           unsigned long long seed, float *sink)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const unsigned long long wave = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    for (int it = 0; it < iters; it += U) {
+        v4i r[U][2];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const unsigned long long h = mix(seed + wave * 0x9E3779B97F4A7C15ull + (unsigned long long)(it + j));
+            const long long row = (long long)(h % (unsigned long long)window_rows);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src) + row * 512, 0, 2048, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 2; k++) r[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + k * 1024, 0, AUX);
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) acc += __builtin_bit_cast(v4f, r[j][k]);
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;
+}
+
 }  // namespace
+
+extern "C" int probe_rows_policy(const float *src, long long window_rows, int waves, int iters, unsigned long long seed,
+                                 float *sink, int aux, void *stream)
+{
+    if (!src || !sink || window_rows <= 0 || waves <= 0 || iters <= 0) return 1;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+#define VP_POL(A) case A: hipLaunchKernelGGL(k_probe_rows_policy<A>, grid, dim3(256), 0, (hipStream_t)stream, src, window_rows, iters, seed, sink); break
+    switch (aux) { VP_POL(0); VP_POL(1); VP_POL(2); VP_POL(3); VP_POL(16); VP_POL(17); VP_POL(18); VP_POL(19); default: return 1; }
+#undef VP_POL
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 extern "C" int probe_rows_store(const float *src, long long first_row, long long window_rows, int row_bytes, int waves, int iters,
                                 unsigned long long seed, float *sink, float *dst, long long dst_rows, int store_mode, void *stream)
