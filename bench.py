@@ -232,6 +232,18 @@ def cpu_torch_loop(scene, n_views, n_threads):
                 sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {inb} centres in bounds")
 
 
+def plan_calls(n_views, H, W, C, esize, chunk=0, call_gb=66.0, min_calls=2, pool=32):
+    """(views per call, number of calls, resident maps) for a rank that projects ``n_views`` views: --chunk, or as many views
+    as hold --call-gb of feature maps; at least --min-calls calls; then the views are spread evenly over the calls; the pool
+    holds a whole number of calls' worth of maps (at least one call's)."""
+    per_call = chunk if chunk > 0 else max(1, int(round(call_gb * 1e9 / (H * W * C * esize))))
+    per_call = max(1, min(per_call, n_views))
+    n_calls = max(-(-n_views // per_call), min(min_calls, n_views))
+    per_call = -(-n_views // n_calls)
+    resident = max(per_call, (min(max(pool, per_call), n_views) // per_call) * per_call)
+    return per_call, n_calls, resident
+
+
 def device_info(dev):
     """Which GPU a line was measured on: the speed level of a run follows the box as much as the allocation."""
     p = torch.cuda.get_device_properties(dev)
@@ -500,11 +512,7 @@ def main():
     my_views = views_of_rank(n_views, rank, world)
     esize = 4 if a.dtype == "f32" else 2
     # views per call: --chunk, or as many as hold --call-gb of maps; then the rank's views are spread evenly over its calls
-    chunk = a.chunk if a.chunk > 0 else max(1, int(round(a.call_gb * 1e9 / (H * W * C * esize))))
-    chunk = max(1, min(chunk, len(my_views)))
-    n_calls = max(-(-len(my_views) // chunk), min(a.min_calls, len(my_views)))
-    chunk = -(-len(my_views) // n_calls)
-    pool = max(chunk, (min(max(a.pool, chunk), len(my_views)) // chunk) * chunk)
+    chunk, n_calls, pool = plan_calls(len(my_views), H, W, C, esize, a.chunk, a.call_gb, a.min_calls, a.pool)
 
     alloc_kind = {}
 
