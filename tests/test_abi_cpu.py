@@ -30,6 +30,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.vp_abi_version() == 3
 
 
+def test_workspace_record_calls_validate_their_arguments_on_the_host():
+    """vp_workspace_create / _set_option / _release keep host-side records only: their argument checks run without a GPU."""
+    import voxproj_host
+    lib = voxproj_host.lib()
+    vp = ctypes.c_void_p
+    assert lib.vp_workspace_create(vp(None), 1 << 20) == -1                         # VP_EINVAL: null workspace
+    assert b"null" in lib.vp_last_error()
+    assert lib.vp_workspace_create(vp(0x1000_0010), 1 << 20) == -2                  # VP_EWORKSPACE: not 256-byte aligned
+    assert lib.vp_workspace_create(vp(0x1000_0000), 100) == -2                      # too small for the header
+    assert lib.vp_workspace_set_option(vp(None), voxproj_host.VP_OPT_HEAVY_THRESHOLD, 5) == -1
+    fake = vp(0x7000_0000_0000)                                                     # never dereferenced by these calls
+    assert lib.vp_workspace_create(fake, 1 << 20) == 0
+    assert lib.vp_workspace_set_option(fake, voxproj_host.VP_OPT_HEAVY_THRESHOLD, 5) == 0
+    assert lib.vp_workspace_set_option(fake, voxproj_host.VP_OPT_MARCH_LDS_KB, -1) == 0
+    assert lib.vp_workspace_set_option(fake, 99, 1) == -1 and b"unknown workspace option" in lib.vp_last_error()
+    assert lib.vp_workspace_table_builds(fake) == 0
+    assert lib.vp_workspace_release(fake) == 0 and lib.vp_workspace_release(fake) == 0      # releasing twice is harmless
+
+
 def test_workspace_bytes_is_pure_host_arithmetic():
     import voxproj_host
     n = voxproj_host.workspace_bytes(1, 2, 48, 64, 16, 10, 20, 30, 1001)
