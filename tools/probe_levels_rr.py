@@ -30,6 +30,8 @@ ap.add_argument("--soak", type=float, default=0.0)
 ap.add_argument("--workspaces", type=int, default=4)
 ap.add_argument("--tag", default="rr")
 ap.add_argument("--f16", action="store_true")
+ap.add_argument("--pool-flags", default="", help="comma list, one per pool copy: hipExtMallocWithFlags flags (1 fine-grained, "
+                "3 uncached, 4 contiguous; 0 = torch's allocator) -- does the memory TYPE of the pool reproduce a level?")
 ap.add_argument("libs", nargs="*")
 a = ap.parse_args()
 libs = [os.path.abspath(p) for p in a.libs] or [voxproj_host.LIB_PATH]
@@ -58,8 +60,13 @@ make_features_torch(V, H, W, C, dev, seed=0, out=first[0])
 if a.f16:
     first = first.half()
 pools = [first]
+pflags = [int(v) for v in a.pool_flags.split(",") if v]
 for k in range(1, a.allocs):
-    p = torch.empty_like(first)
+    fl = pflags[k] if k < len(pflags) else 0
+    if fl:
+        p, _ = voxproj_host.resident_empty(tuple(first.shape), first.dtype, dev, fallback=False, flags=fl)
+    else:
+        p = torch.empty_like(first)
     p.copy_(first)
     pools.append(p)
 outs = [(torch.zeros(n_vox + 1, C, device=dev), torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)) for _ in pools]
