@@ -17,6 +17,7 @@ import aggregate_voxel_features_onthefly as agg  # noqa: E402
 from synthetic_scene import make_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+PREFETCH = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 3]     # feeder depths to time
 C, h, w = 512, 360, 540
 s = make_scene(87319, N, 876, 584, seed=0)
 tmp = tempfile.mkdtemp(prefix="vp_entry_")
@@ -58,7 +59,7 @@ try:
         return time.perf_counter() - t0
 
     for mode in ("parity", "fast"):
-        for pf in (0, 3):
+        for pf in PREFETCH:
             out = os.path.join(tmp, f"{mode}_{pf}")
             few = run(mode, pf, max(2, N // 4), out + "_few")       # fixed costs (PLY parse, tables, final files) cancel
             t = run(mode, pf, N, out)
@@ -68,8 +69,8 @@ try:
             # difference figure above also carries the result files, whose size grows with the views
             tm = loops[(mode, pf, N)]
             res[f"{mode}_prefetch{pf}_loop_ms_per_view"] = round(tm["loop_s"] / tm["views"] * 1e3, 2)
-        a = torch.load(os.path.join(tmp, f"{mode}_0", f"ALL_nonzero_voxel_features_{N}_vox{s.n_vox}.pt"))
-        b = torch.load(os.path.join(tmp, f"{mode}_3", f"ALL_nonzero_voxel_features_{N}_vox{s.n_vox}.pt"))
+        a = torch.load(os.path.join(tmp, f"{mode}_{PREFETCH[0]}", f"ALL_nonzero_voxel_features_{N}_vox{s.n_vox}.pt"))
+        b = torch.load(os.path.join(tmp, f"{mode}_{PREFETCH[-1]}", f"ALL_nonzero_voxel_features_{N}_vox{s.n_vox}.pt"))
         res[f"{mode}_same_result"] = bool(torch.equal(a["avg_feats"], b["avg_feats"]) and torch.equal(a["voxel_coords"], b["voxel_coords"]))
     print(json.dumps(res))
 finally:
