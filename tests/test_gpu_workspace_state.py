@@ -135,3 +135,55 @@ def test_options_belong_to_the_workspace(oracle_mod):
     with pytest.raises(voxproj_host.VoxprojError, match="unknown workspace option"):
         voxproj_host.check(voxproj_host.lib().vp_workspace_set_option(ws_a.ptr(), 99, 1))
     ws_a.release(); ws_b.release()
+
+
+def test_two_threads_on_two_workspaces(oracle_mod):
+    """The library's records are per workspace and its registry is mutex-guarded: two host threads, each with its own
+    workspace, stream and outputs, issue pipelined calls at the same time (ctypes releases the GIL during the foreign call)
+    and both get the oracle's counts and bit-identical sums."""
+    import threading
+
+    import voxproj_host
+    dev = torch.device(DEV)
+    jobs = []
+    for seed in (111, 113):
+        s, feats, t = _scene(seed=seed, V=6)
+        n_rows, C = s.n_vox + 1, feats.shape[-1]
+        ref_c, ref_o = np.zeros(n_rows, np.int32), np.zeros((n_rows, C), np.float32)
+        for _ in range(4):
+            for a, b in ((0, 2), (2, 6)):
+                oracle_mod.project_features(feats[:, a:b], s.occ[None].astype(np.int64), s.c2w[a:b].reshape(-1), s.intr[None], s.opts(),
+                                            s.grid_origin, s.voxel_size, ref_c, ref_o)
+        jobs.append(dict(s=s, t=t, ref_c=ref_c, ref_o=ref_o, n_rows=n_rows, C=C, err=None,
+                         count=torch.zeros(n_rows, dtype=torch.int32, device=dev), out=torch.zeros(n_rows, C, device=dev),
+                         vm=[t["vmi"].reshape(-1, 16)[a:b].reshape(-1).contiguous() for a, b in ((0, 2), (2, 6))]))
+    torch.cuda.synchronize()
+    start = threading.Barrier(2)
+
+    def work(j):
+        try:
+            torch.cuda.set_device(dev)
+            ws = voxproj_host.Workspace()
+            stream = torch.cuda.Stream(dev)
+            start.wait()
+            with torch.cuda.stream(stream):
+                for _ in range(4):
+                    for k, (a, b) in enumerate(((0, 2), (2, 6))):
+                        voxproj_host.project_features_raw(j["t"]["feats"][:, a:b], j["t"]["occ"], j["vm"][k], j["t"]["intr"], j["t"]["opts"],
+                                                          j["count"], j["out"], j["t"]["origin"], j["s"].voxel_size, workspace=ws,
+                                                          sync=False, pipeline=True)
+                voxproj_host.workspace_status(ws, dev)
+            stream.synchronize()
+            ws.release()
+        except Exception as e:      # surfaced by the main thread
+            j["err"] = e
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    for j in jobs:
+        assert j["err"] is None, j["err"]
+        assert np.array_equal(j["count"].cpu().numpy(), j["ref_c"])
+        assert j["out"].cpu().numpy().tobytes() == j["ref_o"].tobytes()
