@@ -113,6 +113,9 @@ def parse():
     return a
 
 
+PMC_VIEWS_PER_CALL = {"f32": 60, "f16": 100}     # what tools/profile_round.sh passes as --chunk: plan_calls' default for R2
+
+
 def source_digest():
     """sha256 over the library's sources: a PMC profile only describes the kernels it was taken with."""
     import hashlib
@@ -138,12 +141,13 @@ def pmc_traffic(workload, chunk, dtype):
         return None
     run = prof.get("runs", {}).get(dtype)
     # the profile's launches may hold a few views more or fewer than this run's (the per-view figure is what is used)
-    if run is None or prof.get("workload") != workload or abs(prof.get("views_per_call", 0) - chunk) > 4:
+    vpc = (run or {}).get("views_per_call", prof.get("views_per_call", 0))
+    if run is None or prof.get("workload") != workload or abs(vpc - chunk) > 4:
         return None
     if prof.get("source_digest") != source_digest():
         return None
     g = run["k_gather"]
-    return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / prof["views_per_call"]
+    return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / vpc
 
 
 def write_pmc_json(prof_dir, out_path):
@@ -164,11 +168,13 @@ def write_pmc_json(prof_dir, out_path):
                     if k:
                         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if "k_gather" in per:
-            # full 60-view launches only (--views 120 = two of them per pass; the pre-pass and the placement pass repeat them)
-            runs[dt] = {k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), 1),
-                            "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]), 1)} for k, v in per.items()}
+            # full launches only (--views = two of them per pass; the pre-pass and the placement pass repeat them), at the
+            # views per launch the default plan gives that dtype: 60 (fp32) / 100 (fp16)
+            runs[dt] = {"views_per_call": PMC_VIEWS_PER_CALL[dt]}
+            runs[dt].update({k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), 1),
+                            "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]), 1)} for k, v in per.items()})
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --views 120 --chunk 60 [--dtype f16], MI355X (tools/profile_round.sh)",
+                     "--no-cpu-baseline --views 120 --chunk 60 | --views 200 --chunk 100 --dtype f16, MI355X (tools/profile_round.sh)",
            "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane streaming reads -> doubled by the reader "
                    "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; units KB",
            "workload": "R2", "views_per_call": 60, "source_digest": source_digest(), "runs": runs}

@@ -13,7 +13,7 @@ grep '^{' gpurun_out/prof_$tag/bench_under_rocprof.log | tail -1 > $P/${tag}_ben
   echo "# commands (cd \$GRAFT_REPO_ROOT; TMPDIR=/tmp):"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace     -- python3 bench.py --no-cpu-baseline              (same run's JSON line: profiles/${tag}_bench_under_rocprof.json)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_f16 -- python3 bench.py --no-cpu-baseline --dtype f16"
-  echo "#   rocprofv3 --pmc FETCH_SIZE -d <out>/fetch_<dt> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 120 --chunk 60 [--dtype f16]"
+  echo "#   rocprofv3 --pmc FETCH_SIZE -d <out>/fetch_<dt> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 120 --chunk 60   |   --views 200 --chunk 100 --dtype f16"
   echo "#   rocprofv3 --pmc WRITE_SIZE -d <out>/write_<dt> -- (same)      (separate passes; counter passes serialise kernels: their durations are not the bench's)"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace_R4  -- python3 bench.py --workload R4 --no-cpu-baseline"
   echo "# k_gather averages over ALL launches of a process (placement pass 10, pre-pass 5, warm-up 5, timed 15, after-pass 10 = 45 at 5 calls of 60 views per pass);"

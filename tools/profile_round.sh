@@ -10,9 +10,11 @@ out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $out/trace_f16 -o t --output-format csv -- python3 bench.py --no-cpu-baseline --dtype f16 > $out/bench_f16_under_rocprof.log 2>&1 || exit 1
+# two full launches per pass at the views per launch bench.py's default plan gives the dtype (60 fp32 / 100 fp16)
 for dt in f32 f16; do
-  rocprofv3 --pmc FETCH_SIZE -d $out/fetch_$dt -o c --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 120 --chunk 60 --dtype $dt > $out/pmc_fetch_$dt.log 2>&1 || exit 1
-  rocprofv3 --pmc WRITE_SIZE -d $out/write_$dt -o c --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --views 120 --chunk 60 --dtype $dt > $out/pmc_write_$dt.log 2>&1 || exit 1
+  if [ $dt = f16 ]; then shape="--views 200 --chunk 100"; else shape="--views 120 --chunk 60"; fi
+  rocprofv3 --pmc FETCH_SIZE -d $out/fetch_$dt -o c --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $shape --dtype $dt > $out/pmc_fetch_$dt.log 2>&1 || exit 1
+  rocprofv3 --pmc WRITE_SIZE -d $out/write_$dt -o c --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $shape --dtype $dt > $out/pmc_write_$dt.log 2>&1 || exit 1
 done
 rocprofv3 --kernel-trace --stats -d $out/trace_R4 -o t --output-format csv -- python3 bench.py --workload R4 --no-cpu-baseline > $out/bench_R4_under_rocprof.log 2>&1 || exit 1
 python3 tools/summarize_prof.py $out/trace $out/trace_f16 $out/fetch_f32 $out/write_f32 $out/fetch_f16 $out/write_f16 $out/trace_R4 > $out/summary.txt
