@@ -423,6 +423,93 @@ def test_degenerate_and_scaled_poses(oracle_mod):
     _compare(oracle_mod, feats, s.occ[None], c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1)
 
 
+def test_non_finite_poses_and_intrinsics(oracle_mod):
+    # ScanNet marks a frame whose tracking was lost with a pose of -inf; a NaN can come out of a bad calibration file.
+    # The reference marches such rays all the same (K.cu:47-82: every comparison with a NaN is false, the float -> int
+    # conversion of a NaN is 0 and saturates otherwise, so the samples all land in cell (0,0,0) or nowhere); the
+    # oracle restates that, the kernels must neither hang nor differ.  Cell (0,0,0) is occupied in one of the grids.
+    s = make_scene(2000, 5, 40, 24, seed=56, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(5, 24, 40, 8, seed=56)[None]
+    c2w = s.c2w.copy()
+    c2w[0, :, :] = -np.inf                               # ScanNet's "invalid pose"
+    c2w[1, :3, 3] = np.nan                               # position unknown
+    c2w[2, 0, 0] = np.inf                                # one infinite rotation entry
+    c2w[3, 1, 2] = np.nan
+    for corner_id in (0, 7):
+        occ = s.occ[None].copy()
+        occ[0, 0, 0, 0] = corner_id
+        _compare(oracle_mod, feats, occ, c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1, expect_boxmiss=None)
+    for intr in (np.array([0.0, s.intr[1], s.intr[2], s.intr[3]], np.float32),          # fx = 0: directions divide by zero
+                 np.array([s.intr[0], np.nan, s.intr[2], s.intr[3]], np.float32),
+                 np.array([s.intr[0], s.intr[1], np.inf, s.intr[3]], np.float32)):
+        _compare(oracle_mod, feats, s.occ[None], s.c2w, intr, s.opts(), s.grid_origin, s.voxel_size, s.n_vox + 1, expect_boxmiss=None)
+    for opts in (np.array([40, 24, np.nan, 10.0, 0.5 * s.voxel_size], np.float32),      # NaN range: no sample is taken
+                 np.array([40, 24, 0.01, np.inf, 0.5 * s.voxel_size], np.float32)):     # dmax = inf: direction (0,0,NaN)
+        _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, opts, s.grid_origin, s.voxel_size, s.n_vox + 1, expect_boxmiss=None)
+
+
+def test_non_finite_poses_in_job_mode(oracle_mod):
+    # the same nulls through the merged gather (calls of >= 8 views) and the grouped first-tile fetch, pipelined
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 10, 40, 24, seed=58, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(10, 24, 40, 16, seed=58)[None]
+    c2w = s.c2w.copy()
+    c2w[1, :, :] = -np.inf
+    c2w[4, :3, 3] = np.nan
+    c2w[6, 2, 1] = np.inf
+    occ = s.occ[None].astype(np.int64).copy()
+    occ[0, 0, 0, 0] = 9                                   # the cell every NaN sample lands in is occupied
+    n_rows = s.n_vox + 1
+    count, out = np.zeros(n_rows, np.int32), np.zeros((n_rows, 16), np.float32)
+    for _ in range(2):
+        r = oracle_mod.project_features(feats, occ, c2w.reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, count, out)
+    assert r["rc"] == 0 and count[9] >= 2 * 960
+    for f in (feats, feats.astype(np.float16)):
+        if f.dtype == np.float16:
+            count[:] = 0; out[:] = 0
+            for _ in range(2):
+                oracle_mod.project_features(f.astype(np.float32), occ, c2w.reshape(-1), s.intr[None], s.opts(), s.grid_origin,
+                                            s.voxel_size, count, out)
+        count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        out_t = torch.zeros(n_rows, 16, device=dev)
+        ws = voxproj_host.Workspace()
+        args = (torch.from_numpy(f).to(dev), torch.from_numpy(occ).to(dev), torch.from_numpy(c2w).reshape(-1).to(dev),
+                torch.from_numpy(s.intr[None]).to(dev), [float(v) for v in s.opts()], count_t, out_t,
+                [float(v) for v in s.grid_origin], s.voxel_size)
+        for _ in range(2):
+            voxproj_host.project_features_raw(*args, workspace=ws, sync=False, pipeline=True)
+        voxproj_host.workspace_status(ws, dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(count_t.cpu().numpy(), count)
+        assert out_t.cpu().numpy().tobytes() == out.tobytes()
+        ws.release()
+
+
+def test_non_finite_feature_values_propagate_like_the_reference(oracle_mod):
+    # a NaN / Inf in a feature map ends up in exactly the voxels the reference's atomicAdd would poison (AGG:303-304 looks
+    # for them afterwards); compared NaN-for-NaN, since inf - inf makes a NaN whose sign bit is the processor's choice
+    s = make_scene(2000, 3, 40, 24, seed=57, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(3, 24, 40, 8, seed=57)[None]
+    feats[0, 0, 3, 5, 2] = np.nan
+    feats[0, 1, 10, 20, :] = np.inf
+    feats[0, 2, 11, 21, 4] = -np.inf
+    feats[0, 2, 12, 22, 4] = np.inf
+    n_rows = s.n_vox + 1
+    count, out = np.zeros(n_rows, np.int32), np.zeros((n_rows, 8), np.float32)
+    r = oracle_mod.project_features(feats, s.occ[None].astype(np.int64), s.c2w.reshape(-1), s.intr[None], s.opts(), s.grid_origin,
+                                    s.voxel_size, count, out)
+    assert r["rc"] == 0 and np.isnan(out).any() and np.isinf(out).any()
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=DEV)
+    out_t = torch.zeros(n_rows, 8, device=DEV)
+    _gpu_call(feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, count_t, out_t)
+    got = out_t.cpu().numpy()
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    assert np.array_equal(np.isnan(got), np.isnan(out))
+    fin = ~np.isnan(out)
+    assert got[fin].tobytes() == out[fin].tobytes()
+
+
 def test_zero_depth_min_and_coarse_steps(oracle_mod):
     s = make_scene(2000, 2, 40, 24, seed=53, room=(5.0, 4.0, 2.4))
     feats = make_features_np(2, 24, 40, 8, seed=53)[None]
