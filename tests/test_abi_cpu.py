@@ -49,6 +49,46 @@ def test_workspace_record_calls_validate_their_arguments_on_the_host():
     assert lib.vp_workspace_release(fake) == 0 and lib.vp_workspace_release(fake) == 0      # releasing twice is harmless
 
 
+def test_project_features_validates_its_arguments_before_touching_the_device():
+    """Every refusal of vp_project_features[_f16] that the header documents is decided on the host (K.cu:374-414 checks
+    nothing; W.cpp:38-61 checks dtypes only): device pointers here are fakes that are never dereferenced."""
+    import voxproj_host
+    lib = voxproj_host.lib()
+    P = 0x7000_0000_0000                                   # "device" addresses, 256-byte aligned
+    o = (ctypes.c_float * 5)(48, 32, 0.01, 10.0, 0.05)
+    g = (ctypes.c_float * 3)(0, 0, 0)
+    base = dict(feats=P, occ=P + 4096, vmi=P + 8192, intr=P + 12288, opts=o, count=P + 16384, out=P + 20480, views_hit=None,
+                origin=g, vs=0.1, B=1, V=2, H=32, W=48, C=8, dz=10, dy=20, dx=30, n_rows=1001, ws=P + (1 << 20), ws_bytes=1 << 30,
+                stream=None, flags=0)
+
+    def call(entry=lib.vp_project_features, **kw):
+        a = dict(base, **kw)
+        return entry(a["feats"], a["occ"], a["vmi"], a["intr"], a["opts"], a["count"], a["out"], a["views_hit"], a["origin"],
+                     ctypes.c_float(a["vs"]), a["B"], a["V"], a["H"], a["W"], a["C"], a["dz"], a["dy"], a["dx"], a["n_rows"],
+                     a["ws"], a["ws_bytes"], a["stream"], a["flags"])
+
+    cases = [
+        (dict(feats=None), -1, b"null pointer"), (dict(count=None), -1, b"null pointer"), (dict(ws=None), -1, b"null pointer"),
+        (dict(V=0), -1, b"non-positive"), (dict(C=-3), -1, b"non-positive"), (dict(n_rows=0), -1, b"non-positive"),
+        (dict(B=256, V=257), -1, b"exceeds 65535"),
+        (dict(dz=2048, dy=1024, dx=1024), -1, b"2^31 cells"),
+        (dict(H=65536, W=32768, opts=(ctypes.c_float * 5)(32768, 65536, 0.01, 10.0, 0.05)), -1, b">= 2^31"),
+        (dict(n_rows=1 << 31), -1, b">= 2^31"),
+        (dict(flags=voxproj_host.VP_FLAG_SYNC | voxproj_host.VP_FLAG_PIPELINE), -1, b"exclude each other"),
+        (dict(opts=(ctypes.c_float * 5)(47, 32, 0.01, 10.0, 0.05)), -1, b"must equal the feature map"),
+        (dict(opts=(ctypes.c_float * 5)(48, 32, 0.01, 10.0, 0.0)), -1, b"rayIncrement must be > 0"),
+        (dict(opts=(ctypes.c_float * 5)(48, 32, 0.01, 10.0, float("nan"))), -1, b"rayIncrement must be > 0"),
+        (dict(ws_bytes=4096), -2, b"need"), (dict(ws=P + (1 << 20) + 16), -2, b"256-byte aligned"),
+    ]
+    for kw, rc, msg in cases:
+        assert call(**kw) == rc, kw
+        assert msg in lib.vp_last_error(), (kw, lib.vp_last_error())
+    f16 = lib.vp_project_features_f16
+    assert call(f16, C=12) == -1 and b"C % 8 == 0" in lib.vp_last_error()
+    assert call(f16, out=P + 20480 + 4) == -1 and b"16-byte aligned" in lib.vp_last_error()
+    assert call(f16, feats=None) == -1 and b"null pointer" in lib.vp_last_error()
+
+
 def test_workspace_bytes_is_pure_host_arithmetic():
     import voxproj_host
     n = voxproj_host.workspace_bytes(1, 2, 48, 64, 16, 10, 20, 30, 1001)
