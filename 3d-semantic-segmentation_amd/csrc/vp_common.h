@@ -152,8 +152,16 @@ void ws_forget(const void *workspace)
 bool pipe_open(PipeState &ps)
 {
     if (ps.ok) return true;
-    // (a high-priority side stream was measured: no effect on the pipelined step time, so plain streams)
-    bool ok = hipStreamCreateWithFlags(&ps.side, hipStreamNonBlocking) == hipSuccess;
+    // The side stream is created with the device's highest priority -- not for the scheduling (measured: no effect on the
+    // pipelined step time) but for its HARDWARE QUEUE.  The runtime multiplexes a process's streams onto a few HSA queues
+    // per priority level (GPU_MAX_HW_QUEUES, 4 by default), handing a new stream the least-used one.  A process that has
+    // initialised RCCL through torch.distributed first (a pool of 32 streams per level) gets, for a normal-priority side
+    // stream, the very queue the caller's stream sits on: the march of call j+1 then queues up BEHIND the gather of call
+    // j instead of running under it and a 300-view R2 pass takes 63 ms instead of 54 (profiles/r03_hw_queue_sharing.log;
+    // GPU_MAX_HW_QUEUES=1 reproduces it without RCCL).  Queues of another priority level come from another pool.
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_greatest = 0; }
+    bool ok = hipStreamCreateWithPriority(&ps.side, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     for (int q = 0; q < 2 && ok; q++)
         ok = hipEventCreateWithFlags(&ps.fh_done[q], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ps.call_done[q], hipEventDisableTiming) == hipSuccess;

@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
             work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
 }
 
-// MERGED = true: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of 8 or more views); 97 VGPRs,
-// i.e. 4 wavefronts per SIMD -- in pipelined mode a gain, because a fifth gather wave would take the room the next call's
+// MERGED = true: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of 8 or more views); 101-106 VGPRs
+// (97 before round 3's write-through row stores and grouped tile fetch; allocated 104-112 either way), i.e. 4 wavefronts per SIMD -- in pipelined mode a gain, because a fifth gather wave would take the room the next call's
 // march needs (forcing <= 96 registers with __launch_bounds__(256, 5), one allocation: pipelined +2.5 % fp16 / +2 % R1 /
 // -0.4 % fp32; serial phases -1.0 .. -1.4 %).
 // MERGED = false: without that role the kernel needs 96 VGPRs = 5 wavefronts per SIMD, worth 5 % on a one-view call

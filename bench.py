@@ -84,6 +84,10 @@ def parse():
     ap.add_argument("--cpu-views", type=int, default=8, help="views in the cpu_baseline sample")
     ap.add_argument("--dtype", default="f32", choices=("f32", "f16"), help="feature-map storage type; f32 is the "
                     "BASELINE metric config, f16 the lossless half-bandwidth mode of SURVEY 8f/n4 (extra, not the headline)")
+    ap.add_argument("--rehearse-dist", action="store_true", help="with one process: create the process group anyway (RCCL "
+                    "communicator of ONE rank) and run the multi-rank code path -- collective inside the pass, verification, "
+                    "overlapped passes -- on a one-GPU box.  A rehearsal of the control flow and of the RCCL calls, not a "
+                    "scaling number: a one-rank collective moves nothing over xGMI")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -492,7 +496,10 @@ def main():
     dev = torch.device("cuda", 0 if a.single_device else local)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world == 1 and a.rehearse_dist:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+    if world > 1 or a.rehearse_dist:
         import torch.distributed as dist
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -776,7 +783,8 @@ def main():
                        "views_per_call": chunk, "resident_feature_maps": pool,
                        "parallelism": (f"views r::{world} per GPU + one RCCL {'reduce to rank 0' if a.collective == 'reduce' else 'all-reduce'} of sum/count "
                                        f"per pass, waited for inside the pass (backend {a.dist_backend})")
-                       if world > 1 else "single GPU"},
+                       if world > 1 else "single GPU (one-rank process group: rehearsal of the multi-rank path)" if dist is not None
+                       else "single GPU"},
             "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
             "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
                                   "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
@@ -792,7 +800,7 @@ def main():
                 "overlapped_passes": (None if overlapped is None else
                                       {"ms_per_step": round(overlapped * 1e3, 3), "value": round(n_vox * n_views / overlapped / 1e6, 3),
                                        "what": "extra: collective of pass k overlapped with the projection of pass k+1 (two output "
-                                               "buffers), what a job streaming many scenes sees; never the headline"})} if world > 1 else {}),
+                                               "buffers), what a job streaming many scenes sees; never the headline"})} if dist is not None else {}),
             "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "heavy_pixels_per_step": heavy_px, "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),

@@ -138,3 +138,40 @@ def test_bench_contiguous_allocation_option():
     d = _last_json(r.stdout)
     assert set(d["pool_placement"]["allocation"].values()) <= {"contiguous", "default"}
     assert d["pool_placement"]["allocation"]["feature_pool"] == "contiguous" and d["value"] > 0
+
+
+def _overlapped(d):
+    """Phase 1 of call j+1 really ran UNDER the gather of call j: beside a gather the (throttled) march takes several times
+    its solo time, so the sum of the phases' own durations exceeds the pass by far; when the two streams share a hardware
+    queue the phases run one after the other and the pass IS their sum."""
+    ph = d["phase_ms_per_step"]
+    return d["ms_per_step"] < 0.9 * (ph["first_hit"] + ph["gather"])
+
+
+def test_job_mode_overlap_survives_a_single_hardware_queue():
+    """The runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level; with ONE queue
+    a normal-priority side stream lands on the caller's queue and the march queues up behind the gather (R2 pass 64.8 ms
+    instead of 52, profiles/r03_hw_queue_sharing.log).  The library's side stream has the device's highest priority: its
+    queue comes from another pool, whatever the process created before."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["phase_ms_per_step"]["overlapped"] is True and _overlapped(d), (d["ms_per_step"], d["phase_ms_per_step"])
+
+
+def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
+    """`--rehearse-dist`: the N > 1 control flow of bench.py (collective inside the pass, exact verification of the reduced
+    counts, overlapped passes) with backend nccl = RCCL and ONE rank -- the only way RCCL can run this code on a one-GPU
+    box.  RCCL initialised before the first pipelined call used to cost the march/gather overlap (63 vs 54 ms per R2
+    pass): asserted here on the R1 workload."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--rehearse-dist"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["collective"]["backend"] == "nccl" and d["collective"]["op"] == "all-reduce"
+    assert d["collective"]["collective_ms_exposed"] >= 0 and d["overlapped_passes"]["value"] > 0
+    assert d["reduced_hit_pixels"] == d["hit_pixels_per_step"]
+    assert "rehearsal" in d["config"]["parallelism"] and "cpu_baseline" not in d
+    assert _overlapped(d), (d["ms_per_step"], d["phase_ms_per_step"])
