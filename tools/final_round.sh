@@ -9,10 +9,13 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 echo "[final] gpu tests $(date +%T)"
 timeout -k 10 900 python3 -m pytest tests -m gpu -q > gpurun_out/${tag}_gputest.log 2>&1; echo "[final] pytest rc $?"; tail -n 3 gpurun_out/${tag}_gputest.log
-echo "[final] benches $(date +%T)"
-timeout -k 10 1200 bash tools/run_benches.sh $tag || echo "[final] run_benches failed"
+# counter passes first: the bench legs after them find profiles/${tag}_pmc_traffic.json stamped with THIS build's digest and
+# report roofline.traffic
 echo "[final] profile round $(date +%T)"
 timeout -k 10 1500 bash tools/profile_round.sh $tag || echo "[final] profile_round failed"
+cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
+echo "[final] benches $(date +%T)"
+timeout -k 10 1200 bash tools/run_benches.sh $tag || echo "[final] run_benches failed"
 echo "[final] auxiliary $(date +%T)"
 timeout -k 10 300 python3 tools/bench_prep.py > gpurun_out/${tag}_bench_prep.log 2>&1
 timeout -k 10 300 python3 tools/bench_dropin.py > gpurun_out/${tag}_bench_dropin.log 2>&1

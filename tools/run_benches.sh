@@ -12,3 +12,4 @@ python3 bench.py --entry parity --no-cpu-baseline > $o/${tag}_bench_entry_parity
 python3 bench.py --entry parity --entry-no-pipeline --no-cpu-baseline > $o/${tag}_bench_entry_parity_unpipelined.log 2>&1 || exit 1
 python3 bench.py --entry fast --no-cpu-baseline > $o/${tag}_bench_entry_fast.log 2>&1 || exit 1
 python3 bench.py --no-pipeline --no-cpu-baseline > $o/${tag}_bench_serial.log 2>&1 || exit 1
+python3 bench.py --rehearse-dist --no-cpu-baseline > $o/${tag}_bench_rehearse_dist.log 2>&1 || exit 1
