@@ -74,9 +74,13 @@ def parse():
                     help="feature-map bytes per call the automatic --chunk aims for (SURVEY 8d: chunks of <= 64 resident views, "
                          "69.5 GB).  Every call read-modify-writes the output rows it touches, and those stores cost far more "
                          "than their bytes (DESIGN.md section 4): 60 views per call instead of 30 = +2.7 % on a slow-level box")
-    ap.add_argument("--min-calls", type=int, default=2,
+    ap.add_argument("--min-calls", type=int, default=None,
                     help="cut a rank's views into at least this many calls (in pipelined mode the march of every call but the "
-                         "first hides under the previous gather)")
+                         "first hides under the previous gather).  Default 2 where passes follow one another (one GPU: the "
+                         "first march of pass k+1 hides under the last gather of pass k); 1 in the multi-rank step, where a "
+                         "pass stands alone: its first march is exposed either way, and 38 views of R2 project in 7.91 ms as "
+                         "one call against 8.19 ms as two (the second gather re-reads the output rows and the short launches "
+                         "fill the chip worse; profiles/r03_rank_workloads.log)")
     ap.add_argument("--pool", type=int, default=32, help="distinct resident feature maps")
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -525,7 +529,8 @@ def main():
     my_views = views_of_rank(n_views, rank, world)
     esize = 4 if a.dtype == "f32" else 2
     # views per call: --chunk, or as many as hold --call-gb of maps; then the rank's views are spread evenly over its calls
-    chunk, n_calls, pool = plan_calls(len(my_views), H, W, C, esize, a.chunk, a.call_gb, a.min_calls, a.pool)
+    min_calls = a.min_calls if a.min_calls is not None else (1 if dist is not None else 2)
+    chunk, n_calls, pool = plan_calls(len(my_views), H, W, C, esize, a.chunk, a.call_gb, min_calls, a.pool)
 
     alloc_kind = {}
 

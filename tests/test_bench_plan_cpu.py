@@ -29,6 +29,9 @@ def test_call_plan_at_the_baseline_shapes():
     # config 4: views r::G -- 150 / 75 / 38 / 37 views per rank, evened out over the rank's calls
     assert plan(150, *R2, 4) == (50, 3, 50) and plan(75, *R2, 4) == (38, 2, 38)
     assert plan(38, *R2, 4) == (19, 2, 19) and plan(37, *R2, 4) == (19, 2, 19)
+    # the multi-rank step plans with min_calls = 1: 8 GPUs project their 37-38 views in ONE call, 4 and 2 GPUs are cut by memory
+    assert plan(38, *R2, 4, min_calls=1) == (38, 1, 38) and plan(37, *R2, 4, min_calls=1) == (37, 1, 37)
+    assert plan(75, *R2, 4, min_calls=1) == (38, 2, 38) and plan(150, *R2, 4, min_calls=1) == (50, 3, 50)
     # explicit --chunk / --min-calls / --pool
     assert plan(300, *R2, 4, chunk=32, min_calls=1) == (30, 10, 30)
     assert plan(32, *R2, 4) == (16, 2, 32) and plan(16, *R2, 4) == (8, 2, 16)       # the pool holds all of a short run's views
