@@ -167,7 +167,8 @@ def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
     box.  RCCL initialised before the first pipelined call used to cost the march/gather overlap (63 vs 54 ms per R2
     pass): asserted here on the R1 workload."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--rehearse-dist"], capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--rehearse-dist", "--min-calls", "2"],      # two calls: something to overlap
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["collective"]["backend"] == "nccl" and d["collective"]["op"] == "all-reduce"
