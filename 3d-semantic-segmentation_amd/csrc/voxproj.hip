@@ -304,7 +304,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const bool small_image = merged_heavy && (long long)H * W <= GATHER_G32_SMALL_IMAGE;   // grouping needs views to group
     g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
     if (pipe) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
-    if (!merged_heavy) {
+    // (with VP_FLAG_SERIAL_SUMS no voxel can be heavy: the launch -- 5 us of a 0.1-ms one-view call -- is left out)
+    if (!merged_heavy && heavy_t != 2147483647) {
         ProfSpan sp; sp.begin(3, s0);
         VP_DISPATCH_KVU(k_gather_heavy, vec_ok, C, dim3(HEAVY_BLOCKS), dim3(GW_ALONE * 64), 0, s0, g, p);
         sp.end();
