@@ -136,9 +136,23 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     WsState *st = ws_state(workspace, true);
     PipeState *ps = &st->pipe;
     if (pipe && !pipe_open(*ps)) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
+    // VP_FLAG_GATHER_ONLY: phase 2 once more, on another row range, from what the previous call's phase 1 left in ITS
+    // buffer set; everything runs on the caller's stream, behind that call's gather
+    const bool gather_only = (flags & VP_FLAG_GATHER_ONLY) != 0;
+    if (gather_only) {
+        if (!st->has_hit || st->last_feats != (const void *)feats || st->last_f16 != feats_f16 || st->last_B != B || st->last_V != V ||
+            st->last_H != H || st->last_W != W || st->last_C != C || st->B != B || st->dimz != dimz || st->dimy != dimy ||
+            st->dimx != dimx || st->n_rows != n_rows)
+            return fail(VP_EINVAL, "VP_FLAG_GATHER_ONLY repeats phase 2 of the previous call on this workspace: there is none, or "
+                                   "its feature maps / shapes differ from this call's");
+        if (st->opt_row_begin < 0 && st->opt_row_end < 0)
+            return fail(VP_EINVAL, "VP_FLAG_GATHER_ONLY without a row range (VP_OPT_ROW_BEGIN / VP_OPT_ROW_END) would gather every row twice");
+    }
     int q = 0;
     hipStream_t s1 = s0;
-    if (pipe) {
+    if (gather_only) {
+        q = st->last_q;
+    } else if (pipe) {
         q = (int)(ps->calls & 1);
         s1 = ps->side;
     } else if (ps->ok && (ps->used[0] || ps->used[1])) {
@@ -168,13 +182,13 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     int *occ_copy = (int *)(ws + l.occ_copy);
     WsState &rec = *st;
     const bool rec_matches = rec.B == B && rec.dimz == dimz && rec.dimy == dimy && rec.dimx == dimx && rec.n_rows == n_rows;
-    const bool verify = (flags & VP_FLAG_VERIFY_ACCEL) && !pipe && !(flags & VP_FLAG_REUSE_ACCEL);
+    const bool verify = (flags & VP_FLAG_VERIFY_ACCEL) && !pipe && !gather_only && !(flags & VP_FLAG_REUSE_ACCEL);
     const int cmp_blocks = (int)((cells * B + 255) / 256 > 8192 ? 8192 : (cells * B + 255) / 256);
-    bool rebuild = !(flags & VP_FLAG_REUSE_ACCEL);
+    bool rebuild = !gather_only && !(flags & VP_FLAG_REUSE_ACCEL);
     // VP_FLAG_REUSE_ACCEL is a promise about the tables in THIS workspace: refuse it when the library never built
     // them here (fresh or recycled memory) or built them for another grid shape / row count -- the march would leap on
     // garbage and silently miss hits
-    if (!rebuild && (rec.builds == 0 || !rec_matches))
+    if (!rebuild && !gather_only && (rec.builds == 0 || !rec_matches))
         return fail(VP_EINVAL, "VP_FLAG_REUSE_ACCEL, but this workspace holds no occupancy tables for a grid of this shape "
                                "(B, dims, n_rows): call once without the flag");
     if (rebuild || !rec.opened) {
@@ -231,26 +245,38 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     }
     const unsigned expect_tables = tables_key(rec.B, rec.dimz, rec.dimy, rec.dimx, rec.n_rows, rec.builds);
 
-    if (pipe) {
+    if (pipe && !gather_only) {
         // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
         if (ps->used[q]) VP_HIP(hipStreamWaitEvent(s1, ps->call_done[q], 0));
     }
+    // Row range of phase 2 (VP_OPT_ROW_BEGIN / _END).  While one is set no voxel takes the workgroup path: the heavy list
+    // is the march's, i.e. the whole call's, and the two gathers of a split call must not both work through it.
+    const bool ranged = rec.opt_row_begin >= 0 || rec.opt_row_end >= 0;
+    const long long row_lo = std::max<long long>(1, rec.opt_row_begin);
+    const long long row_hi = rec.opt_row_end < 0 ? (long long)n_rows : std::min<long long>(rec.opt_row_end, (long long)n_rows);
 
     // ---- phase 1 (on s1) ----
     int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
     if (rec.opt_heavy_t > 0) heavy_t = (int)std::min<long long>(rec.opt_heavy_t, 2147483647ll);   // VP_OPT_HEAVY_THRESHOLD
-    if (flags & VP_FLAG_SERIAL_SUMS) heavy_t = 2147483647;
+    if ((flags & VP_FLAG_SERIAL_SUMS) || ranged || gather_only) heavy_t = 2147483647;
 #ifdef VP_DIAG
     if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
 #endif
-    {
+    const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
+    if (gather_only) {
+        // the work list of the new row range, from the histogram the previous call's march left
+        VP_HIP(hipMemsetAsync(status + ST_WORK0, 0, WORK_CLASSES * sizeof(int), s0));
+        hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, s0, (const int *)cnt_call, heavy_t,
+                           (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi);
+    }
+    if (!gather_only) {
         ProfSpan sp; sp.begin(0, s1);
         // one launch clears the per-call status words and the per-call histogram, and checks the workspace header
         hipLaunchKernelGGL(k_zero_call, dim3((unsigned)((n_rows + 1023) / 1024)), dim3(256), 0, s1, status, cnt_call, (long long)n_rows,
                            (const int *)status0, status0, WS_MAGIC, rec.gen, expect_tables);
         sp.end();
     }
-    {
+    if (!gather_only) {
         FirstHitArgs fa;
         fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
         fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
@@ -283,17 +309,16 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // the gather's work list: touched voxels by size class, largest first (needs the finished histogram); its trailing
         // workgroups compute the view table, which is phase 2's too -- behind the march, not in front of it (in pipelined
         // mode a kernel with that many registers waits for a wavefront of the previous call's gather to retire)
-        const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
         hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, s1, (const int *)cnt_call, heavy_t,
-                           (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V);
+                           (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi);
         sp.end();
     }
-    if (pipe) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
+    if (pipe && !gather_only) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
 
     // ---- phase 2 ----
     GatherArgs g;
     g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
-    g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
+    g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + (gather_only ? ST_ZERO : ST_NHEAVY);
     g.work = work; g.work_n = status + ST_WORK0;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
@@ -303,7 +328,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const bool merged_heavy = (long long)B * V >= 8;
     const bool small_image = merged_heavy && (long long)H * W <= GATHER_G32_SMALL_IMAGE;   // grouping needs views to group
     g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
-    if (pipe) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
+    if (pipe && !gather_only) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
     // (with VP_FLAG_SERIAL_SUMS no voxel can be heavy: the launch -- 5 us of a 0.1-ms one-view call -- is left out)
     if (!merged_heavy && heavy_t != 2147483647) {
         ProfSpan sp; sp.begin(3, s0);
@@ -320,13 +345,16 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         sp.end();
     }
     if (pipe) {
+        // (a gather-only call re-records the event of the set it shares with its predecessor and does not advance the sets)
         VP_HIP(hipEventRecord(ps->call_done[q], s0));
         ps->used[q] = true;
         ps->last_q = q;
-        ps->calls++;
-    } else {
+        if (!gather_only) ps->calls++;
+    } else if (!gather_only) {
         ps->last_q = 0;
     }
+    st->last_B = B; st->last_V = V; st->last_H = H; st->last_W = W; st->last_C = C; st->last_q = q;
+    st->last_f16 = feats_f16; st->last_feats = (const void *)feats;
     VP_HIP(hipGetLastError());
     if (flags & VP_FLAG_SYNC) return vp_workspace_status(workspace, stream_);
     return VP_OK;
@@ -644,6 +672,8 @@ int vp_workspace_set_option(void *workspace, int option, long long value)
     switch (option) {
     case VP_OPT_HEAVY_THRESHOLD: rec->opt_heavy_t = value > 0 ? value : -1; return VP_OK;
     case VP_OPT_MARCH_LDS_KB:    rec->opt_march_lds_kb = value >= 0 ? value : -1; return VP_OK;
+    case VP_OPT_ROW_BEGIN:       rec->opt_row_begin = value >= 0 ? value : -1; return VP_OK;
+    case VP_OPT_ROW_END:         rec->opt_row_end = value >= 0 ? value : -1; return VP_OK;
     default: return fail(VP_EINVAL, "unknown workspace option %d", option);
     }
 }

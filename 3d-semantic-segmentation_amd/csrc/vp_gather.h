@@ -576,9 +576,11 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
 // workspace per voxel row -- because the class sizes are only known once every workgroup has counted.)
 constexpr int WL_PER_THREAD = 16;   // IDs per lane of k_worklist: a 256-thread workgroup bins 4096 voxel IDs
 
+// [row_lo, row_hi): the IDs this call's phase 2 gathers (VP_OPT_ROW_BEGIN / _END; [1, n_rows) when no range is set).
 __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, long long n_rows,
                                                   int *__restrict__ work, int *work_n, int wl_blocks,
-                                                  const float *__restrict__ vmi, ViewEntry *viewtab, int n_views)
+                                                  const float *__restrict__ vmi, ViewEntry *viewtab, int n_views,
+                                                  long long row_lo, long long row_hi)
 {
     if ((int)blockIdx.x >= wl_blocks) {
         // trailing workgroups: the call's view table (phase 2's world->camera maps), one thread per view -- riding on
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
         // consecutive lanes take consecutive IDs, so the ranks inside a class follow the ID order closely
         const long long id = id0 + (long long)j * 256 + threadIdx.x;
         int c = 0;
-        if (id > 0 && id < n_rows) c = cnt_call[id];
+        if (id >= row_lo && id < row_hi) c = cnt_call[id];
         cls[j] = (c > 0 && c <= heavy_t) ? min(WORK_CLASSES - 1, max(0, 28 - __builtin_clz(c))) : -1;     // floor(log2 c) - 3
         rank[j] = cls[j] >= 0 ? atomicAdd(&n_cls[cls[j]], 1) : 0;
     }

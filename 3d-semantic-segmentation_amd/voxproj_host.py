@@ -19,6 +19,7 @@ VP_FLAG_EXACT_MARCH = 4
 VP_FLAG_PIPELINE = 8
 VP_FLAG_VERIFY_ACCEL = 16
 VP_FLAG_SERIAL_SUMS = 32
+VP_FLAG_GATHER_ONLY = 64
 
 _lib = None
 _lock = threading.Lock()
@@ -54,6 +55,8 @@ EXPORTS = [
 VP_ABI_VERSION = 3
 VP_OPT_HEAVY_THRESHOLD = 1
 VP_OPT_MARCH_LDS_KB = 2
+VP_OPT_ROW_BEGIN = 3
+VP_OPT_ROW_END = 4
 
 
 class VoxprojError(RuntimeError):
@@ -205,7 +208,7 @@ class Workspace:
         state = (_options_version, tuple(sorted(self.options.items())))
         if self.buf is None or self._applied == state:
             return
-        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1}
+        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1, VP_OPT_ROW_BEGIN: -1, VP_OPT_ROW_END: -1}
         merged.update(_default_options)
         merged.update(self.options)
         for opt, val in merged.items():
@@ -220,6 +223,13 @@ class Workspace:
         else:
             self.options[int(option)] = int(value)
         self._push_options()
+
+    def set_row_range(self, begin=None, end=None):
+        """Phase 2 of the following calls gathers only the voxel IDs in [begin, end) (VP_OPT_ROW_BEGIN / _END); no arguments:
+        every row again.  With ``project_features_raw(..., gather_only=True)`` a call is cut into row ranges whose output rows
+        are final one range after the other."""
+        self.set_option(VP_OPT_ROW_BEGIN, begin)
+        self.set_option(VP_OPT_ROW_END, end)
 
     def ptr(self):
         return (self.buf.data_ptr() + 255) & ~255
@@ -253,7 +263,7 @@ def get_workspace(device):
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
                          workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False,
-                         views_hit=None, verify_accel=False):
+                         views_hit=None, verify_accel=False, gather_only=False):
     """Call vp_project_features (or vp_project_features_f16 when ``feats`` is float16) on torch CUDA tensors
     (already validated by the caller).
 
@@ -268,7 +278,8 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     int32 [n_rows] tensor, += number of views of this call that hit each voxel.  ``verify_accel``: when the tables
     are not reused by identity (blocking calls only), let the library compare the grid with the copy the tables were
     built from and rebuild only if it changed (VP_FLAG_VERIFY_ACCEL) -- for callers that make a new, equal
-    occupancy tensor for every call.
+    occupancy tensor for every call.  ``gather_only``: VP_FLAG_GATHER_ONLY -- no ray-march, phase 2 of the PREVIOUS call on
+    this workspace (same tensors) once more, for the row range now set with ``Workspace.set_row_range``.
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -285,7 +296,8 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
         exact_march = EXACT_MARCH
     flags = ((VP_FLAG_SYNC if (sync and not pipeline) else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
              | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0)
-             | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel and ACCEL_CACHE) else 0))
+             | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel and ACCEL_CACHE) else 0)
+             | (VP_FLAG_GATHER_ONLY if gather_only else 0))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream

@@ -59,6 +59,12 @@ enum {
                                 serial order of oracle/projector_oracle.c (the heavy path is within 1e-4, not bit-equal).
                                 For callers that round the sums afterwards and promise the reference's bits -- the
                                 aggregator's parity mode (DPF:252 rounds to float16).  Slower only when a voxel is large. */
+    VP_FLAG_GATHER_ONLY = 64,  /* phase 2 only: no ray-march; the first-hit images, the per-call histogram and the view table of
+                                  the PREVIOUS call on this workspace are used again (same arguments, checked) for the row range
+                                  now set with VP_OPT_ROW_BEGIN / VP_OPT_ROW_END.  Two calls -- rows [0, h), then rows [h, n_rows)
+                                  with this flag -- leave exactly what one call leaves, and the rows below h are final while
+                                  the second gather still runs: a multi-GPU job starts their all-reduce under it.  Runs on the
+                                  caller's stream; VP_EINVAL when no call precedes it on the workspace or its shape differs */
     VP_FLAG_VERIFY_ACCEL = 16  /* blocking calls only (ignored with VP_FLAG_PIPELINE or VP_FLAG_REUSE_ACCEL): the
                                 workspace has not been written by anyone else since the previous call on it;
                                 compare the occupancy grid with the 32-bit copy kept from the call that built
@@ -278,8 +284,12 @@ int vp_workspace_release(void *workspace);
  *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
  *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a
  *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise)
+ *   VP_OPT_ROW_BEGIN / _END phase 2 of the following calls gathers only the voxel IDs in [begin, end) (default: all rows;
+ *                           value < 0 restores it).  Phase 1 is not restricted: the histogram it leaves covers every row, so
+ *                           that a VP_FLAG_GATHER_ONLY call can gather the other rows from it.  While a range is set, every
+ *                           voxel is summed by one wavefront in (b, v, y, x) order, as with VP_FLAG_SERIAL_SUMS
  */
-enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2 };
+enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2, VP_OPT_ROW_BEGIN = 3, VP_OPT_ROW_END = 4 };
 int vp_workspace_set_option(void *workspace, int option, long long value);
 
 /* How many times the occupancy-derived tables of this workspace have been (re)built so far (0 if never);
