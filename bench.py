@@ -111,6 +111,9 @@ def parse():
     ap.add_argument("--march-lds-kb", type=int, default=-1,
                     help="experiment: VP_OPT_MARCH_LDS_KB of the workspace (dynamic-LDS reservation of the march = its occupancy "
                          "cap beside a gather); -1 = the library's default (41 KiB = 3 workgroups per CU)")
+    ap.add_argument("--no-split-collective", action="store_true",
+                    help="multi-rank step: do NOT cut the pass's last call into two row ranges (VP_OPT_ROW_BEGIN/_END + "
+                         "VP_FLAG_GATHER_ONLY) whose first half is all-reduced under the second half's gather")
     ap.add_argument("--no-overlap-reduce", action="store_true",
                     help="multi-GPU: skip the extra, overlapped measurement (the collective of pass k on RCCL's stream while "
                          "pass k+1 is projected into a second buffer; reported under 'overlapped_passes').  The headline "
@@ -506,7 +509,9 @@ def main():
     if world > 1 or a.rehearse_dist:
         import torch.distributed as dist
         if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL's kernels on a high-priority stream: its hardware queue is then never the one the projector's gather sits
+            # on, so a collective started under a gather really runs under it
+            dist.init_process_group("nccl", device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
         else:
             dist.init_process_group(a.dist_backend)
         # communicator set-up is lazy: pay it here, not in the first timed step (the driver may pass --warmup 0)
@@ -580,12 +585,12 @@ def main():
 
     pipeline = not a.no_pipeline
 
-    def one_call(ci, sync=False, o=None, c=None):
+    def one_call(ci, sync=False, o=None, c=None, gather_only=False):
         slot, vs = calls[ci]
         voxproj_host.project_features_raw(feats[:, slot:slot + len(vs)], occ, vmis[ci], intr, opts,
                                           count if c is None else c, out if o is None else o,
                                           origin, scene.voxel_size, workspace=ws, sync=sync,
-                                          reuse_accel=(ci > 0 or None), pipeline=(pipeline and not sync))
+                                          reuse_accel=(ci > 0 or None), pipeline=(pipeline and not sync), gather_only=gather_only)
 
     # Placement of the resident buffers (untimed set-up).  Where the driver puts the physical pages of the feature
     # pool and of the output rows moves the gather's speed by several per cent from one allocation to the next
@@ -636,13 +641,37 @@ def main():
                     w.wait()
                 inflight[j] = None
 
+    # Inside a pass the collective can start before the projection ends: the pass's LAST call is cut into two row ranges
+    # (the library gathers voxel IDs [0, h) first, then [h, n_rows) from the same first-hit images), and the rows below h,
+    # final after the first gather, are reduced on RCCL's stream while the second gather runs.  Same bytes on the links, about
+    # half of them hidden; the split itself costs a second, shorter gather launch (measured through --rehearse-dist).
+    split = dist is not None and pipeline and not a.no_split_collective and n_rows > 2
+    h_rows = (n_rows // 2 + 63) & ~63 if split else 0
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def step():
         o, c = bufs[0]
+        t_a = time.perf_counter()
+        ev_a.record()
         c.zero_()
         o.zero_()
-        for ci in range(len(calls)):
+        last = len(calls) - 1
+        for ci in range(last if split else len(calls)):
             one_call(ci, o=o, c=c)
-        if dist is not None:
+        if split:
+            ws.set_row_range(0, h_rows)
+            one_call(last, o=o, c=c)
+            works = reduce_partials(dist, [o[:h_rows]], dst=dst, async_op=True)      # waits for the first gather only
+            ws.set_row_range(h_rows, n_rows)
+            one_call(last, o=o, c=c, gather_only=True)
+            ws.set_row_range()
+            ev_b.record()                                                            # projection done
+            works += reduce_partials(dist, [o[h_rows:], c], dst=dst, async_op=True)
+            for w in works:
+                w.wait()
+            torch.cuda.synchronize(dev)
+            state["exposed_s"] += (time.perf_counter() - t_a) - ev_a.elapsed_time(ev_b) * 1e-3
+        elif dist is not None:
             torch.cuda.synchronize(dev)
             t_proj = time.perf_counter()
             reduce_partials(dist, [o, c], dst=dst)
@@ -773,6 +802,8 @@ def main():
         ms_step = dt / a.steps * 1e3
         value = n_vox * n_views / (dt / a.steps) / 1e6
         launches = max(prof["gather_launches"], 1)
+        if split:
+            launches = a.steps * len(calls)      # the split call's two launches count as the one call whose bytes they move
         gather_ms = prof["gather_ms"] / launches
         ach = (gather_bytes / len(calls)) / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
         # whole-path algorithmic bytes per step: feature rows + output RMW + counts + ID image w+r
@@ -801,7 +832,10 @@ def main():
                                "bytes_per_rank": n_rows * C * 4 + n_rows * 4,
                                "collective_ms_exposed": round(exposed_ms, 3),
                                "projection_ms_per_step": round(ms_step - exposed_ms, 3),
-                               "note": "max over ranks; the headline value includes it (no overlap between passes)"},
+                               "split": ({"rows_reduced_under_the_last_gather": h_rows, "of": n_rows} if split else None),
+                               "note": "max over ranks; the headline value includes it (no overlap between passes" +
+                                       ("; the pass's last call is cut into two row ranges, the first half's rows are reduced under "
+                                        "the second half's gather: collective_ms_exposed = pass - projection" if split else "") + ")"},
                 "overlapped_passes": (None if overlapped is None else
                                       {"ms_per_step": round(overlapped * 1e3, 3), "value": round(n_vox * n_views / overlapped / 1e6, 3),
                                        "what": "extra: collective of pass k overlapped with the projection of pass k+1 (two output "

@@ -52,6 +52,9 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert 0 < d["collective"]["collective_ms_exposed"] < d["ms_per_step"]
     assert d["overlapped_passes"]["value"] > 0
     assert d["hit_pixels_per_step"] > 0 and d["value"] > 0
+    # the pass's last call is cut into two row ranges; the first half's rows are reduced under the second half's gather
+    sp = d["collective"]["split"]
+    assert 0 < sp["rows_reduced_under_the_last_gather"] < sp["of"] == 10001
 
 
 def test_bench_two_ranks_allreduce_variant():
@@ -59,11 +62,12 @@ def test_bench_two_ranks_allreduce_variant():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
-                        "--single-device", "--collective", "reduce", "--no-overlap-reduce"],
+                        "--single-device", "--collective", "reduce", "--no-overlap-reduce", "--no-split-collective"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]          # bench verifies reduced counts exactly and sums against the ranks' own
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and "reduce to rank 0" in d["config"]["parallelism"] and d["overlapped_passes"] is None
+    assert d["collective"]["split"] is None
 
 
 def test_bench_two_ranks_at_the_r2_shape():
