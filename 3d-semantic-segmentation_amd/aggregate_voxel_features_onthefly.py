@@ -113,7 +113,10 @@ class VoxelFeatureAggregator:
         if t.is_cuda:
             return t.to(self.dev, torch.float32).contiguous()
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(self.dev)
+            # high priority = a hardware queue from another pool than the projector's stream: in a process that holds many
+            # streams (torch.distributed) a normal-priority stream may be handed the very queue the gather sits on, and this
+            # copy -- waited for on the host -- would queue up behind it
+            self._copy_stream = torch.cuda.Stream(self.dev, priority=-1)
         host = torch.empty(t.shape, dtype=torch.float32, pin_memory=True)
         host.copy_(t)
         with torch.cuda.stream(self._copy_stream):
@@ -352,7 +355,7 @@ class FeatureFeeder:
             futs = [pool.submit(read_piece, fd, view, o, off0 + o, min(self.CHUNK, nbytes - o)) for o in range(0, nbytes, self.CHUNK)]
             return (shape, dtype, nbytes), b, fd, futs
 
-        copy_stream = torch.cuda.Stream(self.dev)
+        copy_stream = torch.cuda.Stream(self.dev, priority=-1)     # a queue of its own (see _to_device_ready)
         with ThreadPoolExecutor(max_workers=self.io_threads) as pool:
             pending = [submit(pool, i) for i in range(min(self.depth, len(self.paths)))]
             for i, p in enumerate(self.paths):

@@ -1,6 +1,6 @@
 """One-off stress of the projector against the CPU oracle: N random configurations (grid, poses inside / outside / next to
 voxels, intrinsics, ray range and increment, channels, views per call, fp32 / fp16 maps, plain / pipelined call sequences,
-heavy thresholds from 3 pixels to none).  IDs, counts and view counts must be exact, sums within 1e-4 of the oracle's
+heavy thresholds from 3 pixels to none, calls cut into voxel-ID ranges).  IDs, counts and view counts must be exact, sums within 1e-4 of the oracle's
 float64 accumulation (bit-identical where no heavy path can be involved).  python tools/stress_differential.py [N] [seed]"""
 import os
 import sys
@@ -72,8 +72,18 @@ for case in range(N):
                 ids = np.unique(r["hits"][b, v]); views[ids[ids > 0]] += 1
         ft = torch.from_numpy(feats).to(dev); ft = ft.half() if f16 else ft
         vm = torch.from_numpy(c2w).reshape(-1).to(dev); keep.append((ft, vm))
-        voxproj_host.project_features_raw(ft, occ_t, vm, intr_t, [float(v) for v in opts], count_t, out_t, [float(v) for v in origin], vs,
-                                          workspace=ws, sync=not pipeline, reuse_accel=None, pipeline=pipeline, views_hit=views_t)
+        # one call, or the same call cut into 2-3 voxel-ID ranges (VP_OPT_ROW_BEGIN/_END + VP_FLAG_GATHER_ONLY)
+        cuts = [0, n_rows]
+        if rng.integers(0, 3) == 0 and n_rows > 4:
+            cuts = sorted({0, n_rows, *[int(c) for c in rng.integers(1, n_rows, int(rng.integers(1, 3)))]})
+        for k in range(len(cuts) - 1):
+            if len(cuts) > 2:
+                ws.set_row_range(cuts[k], cuts[k + 1])
+            voxproj_host.project_features_raw(ft, occ_t, vm, intr_t, [float(v) for v in opts], count_t, out_t, [float(v) for v in origin], vs,
+                                              workspace=ws, sync=not pipeline, reuse_accel=None if k == 0 else True, pipeline=pipeline,
+                                              views_hit=views_t, gather_only=k > 0)
+        if len(cuts) > 2:
+            ws.set_row_range()
         if not pipeline:
             got_hits = voxproj_host.hit_image(ws, dev).cpu().numpy()
             if not np.array_equal(got_hits, r["hits"]):
