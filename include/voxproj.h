@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 3
+#define VP_ABI_VERSION 3   /* additions since 3 that old callers never see: VP_FLAG_GATHER_ONLY, VP_OPT_ROW_BEGIN / _END */
 
 enum {
     VP_OK = 0,
