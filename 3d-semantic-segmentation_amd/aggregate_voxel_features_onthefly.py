@@ -17,12 +17,14 @@ Two modes:
                  (DPF:252), the running per-voxel sum is an fp16 tensor updated with fp16 adds (AGG:309-312),
                  "hit_count" counts VIEWS (AGG:313) and avg = sum / hit_count in fp16 (AGG:385).
                  Rows appear in dict-insertion order: by first view that hit the voxel, then by voxel ID.
-                 This reproduces the reference's file bit for bit (tests/test_aggregator_*.py check it against
+                 This reproduces the reference's file bit for bit (tests/test_gpu_pipeline_rows.py checks it against
                  oracle.aggregate_views).
   --mode fast    multi-view pipelined calls (VP_FLAG_PIPELINE), fp32 sums, pixel counts and view counts kept
                  exactly; avg = fp32 sum / views (the same definition without the per-view fp16 round trips),
                  rows in voxel-ID order; additionally saves sum/count/views in ``*_fp32.pt``.  With torchrun,
-                 rank r projects views r::G and one all-reduce (RCCL) combines {sum, count, views}.
+                 rank r projects views r::G and one SUM collective (RCCL) per tensor combines {sum, count, views};
+                 the rank's last call is cut by voxel ID so that half of the 410 MB of sums travels under the
+                 gather of the other half (add_final_views; ``--no_split_collective`` = one call, then reduce).
 
 Constants below keep the reference's names (AGG:18-29,106,209,318); every one can be overridden on the
 command line, and ``--first_only`` keeps its meaning (AGG:14,112-113).
@@ -124,11 +126,9 @@ class VoxelFeatureAggregator:
         self._copy_stream.synchronize()                  # the copy stream carries nothing else
         return d
 
-    def add_views(self, feats, c2w, intr4):
-        """feats f32 [V,H,W,C] on the GPU, c2w f32 [V,4,4], intr4 f32 [4] (shared by the call's views).  Host tensors are
-        staged without blocking on the projector; device tensors must be ready (not pending on a stream)."""
-        V, H, W, C = feats.shape
-        assert C == self.C
+    def _stage(self, feats, c2w, intr4):
+        """(feats contiguous, c2w on the device and ready, intrinsics on the device, intrinsics key) of one add_views call."""
+        assert feats.shape[-1] == self.C
         if self.dev.type != "cuda":
             raise RuntimeError("VoxelFeatureAggregator.add_views projects on the GPU: there is no CPU path")
         feats = feats.contiguous()
@@ -138,19 +138,32 @@ class VoxelFeatureAggregator:
             intr = self._to_device_ready(intr4.reshape(1, 4))
             if ikey is not None:
                 self._intr_dev[ikey] = intr              # uploaded once per distinct intrinsics
-        c2w = self._to_device_ready(c2w)
+        return feats, self._to_device_ready(c2w), intr, ikey
+
+    def _project_fast(self, feats, vmi, intr, gather_only=False):
+        """One pipelined multi-view projector call of the fast mode into {sum32, count, views} (the row range set on the
+        workspace, if any, applies).  What the library's side stream reads (poses, intrinsics) is kept alive until the next
+        flush: torch's allocator knows nothing about that stream."""
+        V, H, W, C = feats.shape
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append((vmi, intr))
+        voxproj_host.project_features_raw(feats.unsqueeze(0), self.occ, vmi, intr, self._opts(W, H), self.count,
+                                          self.sum32, self.grid_origin, self.voxel_size, workspace=self.ws,
+                                          sync=False, reuse_accel=None, pipeline=True, views_hit=self.views,
+                                          gather_only=gather_only)
+
+    def add_views(self, feats, c2w, intr4):
+        """feats f32 [V,H,W,C] on the GPU, c2w f32 [V,4,4], intr4 f32 [4] (shared by the call's views).  Host tensors are
+        staged without blocking on the projector; device tensors must be ready (not pending on a stream)."""
+        V, H, W, C = feats.shape
+        feats, c2w, intr, ikey = self._stage(feats, c2w, intr4)
         if self.mode == "parity":
             # One projector call per view (DPF runs once per image), then ONE hand-written epilogue over the rows that
             # view hit (vp_aggregate_view_f16): fp32 pixel sums -> fp16 (DPF:252) -> first-time clone / fp16 "+="
             # (AGG:309-312), views += 1 (AGG:313), first_view for the dict order; the epilogue leaves the scratch pair
             # zeroed, so nothing of size [n_rows, C] is filled, cast or blended per view.  Everything is queued on the
             # current stream; nothing blocks until flush().
-            # poses and intrinsics are read by the library's side stream, which torch's allocator knows nothing about: they
-            # are kept alive until the next flush.  The feature maps are read on the caller's stream only, where torch's
-            # stream-ordered reuse is safe, so they are not held.
-            self._keep = getattr(self, "_keep", [])
             vmis = c2w.reshape(V, 16)
-            self._keep.append((vmis, intr))
             if self.n_seen + V > self._nonfinite.numel():
                 self.flush()
                 grown = torch.zeros(2 * (self.n_seen + V), dtype=torch.int32, device=self.dev)
@@ -167,6 +180,13 @@ class VoxelFeatureAggregator:
                                                             flags=voxproj_host.VP_FLAG_SERIAL_SUMS |   # the reference's bits
                                                             (voxproj_host.VP_FLAG_PIPELINE if self.parity_pipeline else 0))
                 self._prep_key = key
+            # poses and intrinsics are read by the library's side stream, which torch's allocator knows nothing about: they
+            # are kept alive until the next flush -- entered AFTER the flushes above, which empty the list (entered
+            # before them, the poses of this very call were dropped again and their block could be handed to the next call's
+            # pose copy while the side stream still read it).  The feature maps are read on the caller's stream only, where
+            # torch's stream-ordered reuse is safe, so they are not held.
+            self._keep = getattr(self, "_keep", [])
+            self._keep.append((vmis, intr))
             for v in range(V):
                 self._prep(feats[v], vmis[v])
                 voxproj_host.aggregate_view_f16(self._sum, self._cnt, self.run16, self.views, self.first_view,
@@ -175,16 +195,39 @@ class VoxelFeatureAggregator:
             if len(self._keep) > 256:
                 self.flush()
         else:
-            # keep what the library's side stream reads alive until the streams are drained (see the parity branch)
-            self._keep = getattr(self, "_keep", [])
-            vmi = c2w.reshape(-1)
-            self._keep.append((vmi, intr))
-            voxproj_host.project_features_raw(feats.unsqueeze(0), self.occ, vmi, intr, self._opts(W, H), self.count,
-                                              self.sum32, self.grid_origin, self.voxel_size, workspace=self.ws,
-                                              sync=False, reuse_accel=None, pipeline=True, views_hit=self.views)
+            self._project_fast(feats, c2w.reshape(-1), intr)
             self.n_seen += V
             if len(self._keep) > 64:
                 self.flush()
+
+    def add_final_views(self, feats, c2w, intr4, dst=None, split=True, on_projected=None):
+        """The rank's LAST call of a scene shared by several ranks (fast mode, torch.distributed initialised) together with
+        the scene's collective -- view_sharding.project_final_call_and_reduce: the call is cut by voxel ID, the feature sums of
+        the rows below the cut are reduced on the collective's stream while the rows above it are still being gathered, the
+        second half and the counts follow; ``split=False`` = the call as it is, then one collective per tensor (the same as
+        add_views + all_reduce).  ``dst`` as in all_reduce.  On return every reduction has completed and ``n_seen`` counts the
+        views of all ranks.  A rank that has no view left for this call passes ``feats=None`` and only joins the collectives."""
+        import torch.distributed as dist
+        from view_sharding import project_final_call_and_reduce, reduce_partials
+        assert self.mode != "parity", "the parity mode is order-dependent (fp16 running sums) and stays on one GPU"
+        staged = None
+        if feats is not None:
+            V = feats.shape[0]
+            f, c, intr, _ = self._stage(feats, c2w, intr4)
+            staged = (f, c.reshape(-1), intr)
+            self.n_seen += V
+
+        def project(gather_only):
+            if staged is not None:
+                self._project_fast(staged[0], staged[1], staged[2], gather_only=gather_only)
+
+        h = project_final_call_and_reduce(dist, project, self.ws.set_row_range, [self.sum32], [self.count, self.views], self.n_rows,
+                                          dst=dst, split=split, on_projected=on_projected)
+        self.flush()
+        n = torch.tensor([self.n_seen], device=self.dev)
+        reduce_partials(dist, [n])
+        self.n_seen = int(n.item())
+        return h
 
     def flush(self):
         """Drain the stream, surface device-side errors, and (parity mode) report the views whose float16 rows held a
@@ -419,6 +462,8 @@ def main(argv=None, timing=None):
     ap.add_argument("--views_per_call", type=int, default=8, help="fast mode: views per projector call")
     ap.add_argument("--half_features", action="store_true", help="fast mode: keep the (fp16-valued) feature maps in "
                     "fp16 on the GPU (vp_project_features_f16): half the HBM traffic, identical results")
+    ap.add_argument("--no_split_collective", action="store_true", help="several ranks: project the rank's last call whole and "
+                    "reduce afterwards (A/B arm of add_final_views' row-range split)")
     ap.add_argument("--prefetch", type=int, default=3, help="feature files read ahead of the GPU by worker threads and "
                     "copied over PCIe on a copy stream (0 = read and copy synchronously)")
     args = ap.parse_args(argv)
@@ -504,19 +549,24 @@ def main(argv=None, timing=None):
             torch.save({k2: r[k2] for k2 in ("xyz", "avg_feats", "hit_count", "voxel_coords")},
                        os.path.join(args.checkpoint_dir, f"checkpoint_features_{idx}.pt"))
             print(f"[CHECKPOINT] Saved consolidated checkpoint data after {idx} images")
-    submit()
-    if timing is not None:
-        if agg is not None:
-            agg.flush()
-        timing.update(loop_s=time.perf_counter() - t_loop, views=len(usable))
     if world > 1:
-        # every rank must reach the all-reduce: agree first that each of them had something to project
+        # every rank must reach the collectives: agree first that each of them had something to project
         ok = torch.tensor([int(agg is not None)], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             raise RuntimeError("a rank had no usable view (fewer views with camera entries than ranks)")
-        agg.all_reduce(dst=0)             # rank 0 alone writes the files: a reduce, not an all-reduce
-    elif agg is None:
+        # the rank's last call and the scene's collective together: rows below the cut are reduced under the gather of the
+        # rows above it.  Rank 0 alone writes the files: a reduce, not an all-reduce
+        last = (ring[slot][:fill], torch.stack(batch_c), batch_intr) if fill else (None, None, None)
+        agg.add_final_views(*last, dst=0, split=not args.no_split_collective)
+        fill, batch_c = 0, []
+    else:
+        submit()
+    if timing is not None:
+        if agg is not None:
+            agg.flush()
+        timing.update(loop_s=time.perf_counter() - t_loop, views=len(usable))
+    if world == 1 and agg is None:
         raise RuntimeError("no view could be processed")
     if rank == 0:
         r = agg.result()

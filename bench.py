@@ -12,9 +12,12 @@ Set-up, untimed: the pool and the output rows are allocated --pool-tries times a
 pass is kept (their physical placement moves the gather by several per cent; every try is in the JSON line under
 "pool_placement", --pool-tries 1 takes the first allocation as it comes).
 
-Multi-GPU (torchrun, one rank per GPU): rank r projects views r::G of the same 300-view scene, then one
-RCCL all-reduce of the per-voxel {feature-sum f32 [N+1,512], hit-count i32 [N+1]} -- total work fixed,
-"scaling": "strong".
+Multi-GPU (one rank per GPU; under torchrun, or started by this file itself: `python bench.py --gpus N` with no WORLD_SIZE in the
+environment runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process before anything touches
+a GPU and exits with its code): rank r projects views r::G of the same 300-view scene through the entry point's own
+VoxelFeatureAggregator (fast mode), then one RCCL all-reduce of the per-voxel {feature-sum f32 [N+1,512], hit-count i32 [N+1],
+view-count i32 [N+1]} -- the rank's last call cut by voxel ID so that half of the sums travel under the other half's gather
+(view_sharding.project_final_call_and_reduce); total work fixed, "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" for the dominant kernel
 (k_gather, HBM-bound; HIP events on its launch stream, recorded live during the timed steps) and
@@ -90,7 +93,7 @@ def parse():
                     "BASELINE metric config, f16 the lossless half-bandwidth mode of SURVEY 8f/n4 (extra, not the headline)")
     ap.add_argument("--rehearse-dist", action="store_true", help="with one process: create the process group anyway (RCCL "
                     "communicator of ONE rank) and run the multi-rank code path -- collective inside the pass, verification, "
-                    "overlapped passes -- on a one-GPU box.  A rehearsal of the control flow and of the RCCL calls, not a "
+                    "both collective arms -- on a one-GPU box.  A rehearsal of the control flow and of the RCCL calls, not a "
                     "scaling number: a one-rank collective moves nothing over xGMI")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse "
                     "the multi-rank code path on a single-GPU box (together with --single-device)")
@@ -112,18 +115,22 @@ def parse():
                     help="experiment: VP_OPT_MARCH_LDS_KB of the workspace (dynamic-LDS reservation of the march = its occupancy "
                          "cap beside a gather); -1 = the library's default (41 KiB = 3 workgroups per CU)")
     ap.add_argument("--no-split-collective", action="store_true",
-                    help="multi-rank step: do NOT cut the pass's last call into two row ranges (VP_OPT_ROW_BEGIN/_END + "
-                         "VP_FLAG_GATHER_ONLY) whose first half is all-reduced under the second half's gather")
-    ap.add_argument("--no-overlap-reduce", action="store_true",
-                    help="multi-GPU: skip the extra, overlapped measurement (the collective of pass k on RCCL's stream while "
-                         "pass k+1 is projected into a second buffer; reported under 'overlapped_passes').  The headline "
-                         "value NEVER overlaps passes: a scene is one pass and pays its collective exposed")
+                    help="multi-rank step: the TIMED arm does not cut the pass's last call into two row ranges (VP_OPT_ROW_BEGIN/_END "
+                         "+ VP_FLAG_GATHER_ONLY) whose first half is all-reduced under the second half's gather.  Either way the "
+                         "other arm is run after the timed region and both are reported (collective.arms)")
+    ap.add_argument("--no-other-arm", action="store_true",
+                    help="multi-rank step: skip the steps of the other collective arm after the timed region")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins a gloo process group, takes its share of the views, plans its calls, and "
+                         "rank 0 prints one line with n_gpus = the group's size (value null).  What tests/ run on CPU to see that "
+                         "`bench.py --gpus N` starts N ranks by itself")
     a = ap.parse_args()
     if a.workload is None:
         a.workload = "R1" if a.entry else "R2"
     return a
 
 
+PMC_PROFILE = "r04_pmc_traffic.json"           # the round's committed counter passes (tools/profile_round.sh writes it)
 PMC_VIEWS_PER_CALL = {"f32": 60, "f16": 100}     # what tools/profile_round.sh passes as --chunk: plan_calls' default for R2
 
 
@@ -140,11 +147,11 @@ def source_digest():
 
 
 def pmc_traffic(workload, chunk, dtype):
-    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json),
+    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json),
     corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
     None unless the profile was taken on this workload / views-per-call / dtype AND with these very kernel sources
     (the file records the digest of csrc/ it was measured on: a stale profile yields null, not a wrong number)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     try:
         with open(path) as f:
             prof = json.load(f)
@@ -162,7 +169,7 @@ def pmc_traffic(workload, chunk, dtype):
 
 
 def write_pmc_json(prof_dir, out_path):
-    """profiles/r03_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
+    """profiles/r04_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
     dtype), stamped with the digest of the kernel sources they were measured on."""
     import collections
     import csv
@@ -488,18 +495,74 @@ def bench_entry(a, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torchrun, rendezvous on
+    127.0.0.1), let rank 0's JSON line through on stdout and exit with the child's code.  Runs before this process has made
+    any GPU call and makes none (torch.cuda.device_count() does not initialise the device on this image): the parent never
+    replaces itself with another program, it waits.  Fewer visible GPUs than ranks is an error -- never a silent one-GPU run."""
+    import socket
+    import subprocess
+    if not a.launch_check:
+        need, have = (1 if a.single_device else a.gpus), torch.cuda.device_count()
+        if have < need:
+            print(f"bench.py --gpus {a.gpus}: needs {need} visible GPU(s), found {have} (one rank per GPU; --single-device "
+                  f"--dist-backend gloo rehearses the multi-rank path on one)", file=sys.stderr)
+            sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.run(cmd, env=env).returncode           # stdout / stderr inherited: rank 0 prints the line
+    sys.exit(rc if rc >= 0 else 1)
+
+
+def launch_check(a, rank, world):
+    """--launch-check: the ranks' rendezvous, view shares and call plans without any GPU work (gloo, CPU tensors)."""
+    import torch.distributed as dist
+    from view_sharding import views_of_rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_vox, n_views, W, H, C = WORKLOADS[a.workload if a.workload in WORKLOADS else "R2"]
+    n_views = a.views or n_views
+    mine = views_of_rank(n_views, rank, world)
+    plan = plan_calls(len(mine), H, W, C, 4 if a.dtype == "f32" else 2, a.chunk, a.call_gb,
+                      a.min_calls if a.min_calls is not None else (1 if world > 1 else 2), a.pool) if mine else (0, 0, 0)
+    t = torch.zeros(world, 3, dtype=torch.int64)
+    t[rank] = torch.tensor([len(mine), plan[0], plan[1]])
+    dist.all_reduce(t)
+    if rank == 0:
+        assert int(t[:, 0].sum()) == n_views
+        print(json.dumps({"metric": "Mvoxel-views/sec", "value": None, "unit": "Mvoxel-views/s", "n_gpus": dist.get_world_size(),
+                          "launch_check": True, "gpus_requested": a.gpus, "views_per_rank": t[:, 0].tolist(),
+                          "views_per_call": t[:, 1].tolist(), "calls_per_rank": t[:, 2].tolist(),
+                          "config": {"workload": a.workload}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == "--write-pmc-json":
         print(json.dumps(write_pmc_json(sys.argv[2], sys.argv[3]))[:300])
         return
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a)                   # the parent: no GPU call before, none after
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU, started by torchrun or by "
+                         f"`python bench.py --gpus {a.gpus}` itself")
+    if a.launch_check:
+        return launch_check(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the projector has no CPU fallback")
+    if not a.single_device and local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local}, {torch.cuda.device_count()} GPU(s) visible")
     dev = torch.device("cuda", 0 if a.single_device else local)
     torch.cuda.set_device(dev)
     dist = None
@@ -514,6 +577,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
         else:
             dist.init_process_group(a.dist_backend)
+        assert dist.get_world_size() == world
         # communicator set-up is lazy: pay it here, not in the first timed step (the driver may pass --warmup 0)
         _t = torch.zeros(1, device=dev)
         dist.all_reduce(_t)
@@ -585,6 +649,26 @@ def main():
 
     pipeline = not a.no_pipeline
 
+    # Multi-rank: the step goes through the entry point's own aggregator (aggregate_voxel_features_onthefly.py, fast mode) --
+    # add_views for every call of the rank but the last, add_final_views for the last call and the scene's collective.  What
+    # the bench times at N > 1 is the code that ships, not a copy of it.
+    agg = None
+    if dist is not None:
+        if not pipeline:
+            raise SystemExit("bench.py: --no-pipeline is a single-process arm; the multi-rank step runs the entry point's "
+                             "aggregator, whose fast mode is always pipelined")
+        from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
+        from view_sharding import split_point
+        agg = VoxelFeatureAggregator(torch.from_numpy(scene.occ), scene.grid_origin.astype(np.float64), scene.voxel_size, C, "fast", dev)
+        assert agg.n_rows == n_rows and agg._opts(W, H) == opts
+        if a.heavy_threshold > 0:
+            agg.ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, a.heavy_threshold)
+        if a.march_lds_kb >= 0:
+            agg.ws.set_option(voxproj_host.VP_OPT_MARCH_LDS_KB, a.march_lds_kb)
+        intr4 = intr.reshape(4)                                     # device tensors: the caller's promise that they are ready
+        c2ws = [c2w[vs].contiguous() for _, vs in calls]
+        torch.cuda.synchronize(dev)
+
     def one_call(ci, sync=False, o=None, c=None, gather_only=False):
         slot, vs = calls[ci]
         voxproj_host.project_features_raw(feats[:, slot:slot + len(vs)], occ, vmis[ci], intr, opts,
@@ -594,15 +678,15 @@ def main():
 
     # Placement of the resident buffers (untimed set-up).  Where the driver puts the physical pages of the feature
     # pool and of the output rows moves the gather's speed by several per cent from one allocation to the next
-    # (tools/probe_placement*.py), stable for the life of the allocation.  A job that will read
-    # the pool for minutes can afford to look: allocate, time one whole pass, park the allocation (so that the next
-    # one lands elsewhere) and try again; the fastest placement is kept, the others are freed.  Every try is reported.
+    # (DESIGN.md section 4), stable for the life of the allocation.  --pool-tries N > 1 is an opt-in search: allocate, time one
+    # whole pass, park the allocation (so that the next one lands elsewhere) and try again; the fastest placement is kept,
+    # the others are freed.  Every try is reported.  (Multi-rank: the output rows are the aggregator's own, one try.)
     placement = {"tries": [], "picked": 0}
     parked, best = [], None
-    for t in range(max(1, a.pool_tries)):
+    for t in range(max(1, a.pool_tries if agg is None else 1)):
         f_try = alloc_pool()
-        c_try = resident((n_rows,), torch.int32, "hit_counts").zero_()
-        o_try = resident((n_rows, C), torch.float32, "output_rows").zero_()
+        c_try = resident((n_rows,), torch.int32, "hit_counts").zero_() if agg is None else agg.count
+        o_try = resident((n_rows, C), torch.float32, "output_rows").zero_() if agg is None else agg.sum32
         feats = f_try
         ms = 0.0
         for rep in range(2):
@@ -624,71 +708,42 @@ def main():
     del parked, best, f_try, c_try, o_try
     torch.cuda.empty_cache()
 
-    # multi-GPU.  The HEADLINE step never overlaps passes: zero, project the rank's views, then the collective, waited for
-    # -- a scene is ONE pass and pays its collective exposed.  The time from "projection done" to "collective done" is
-    # accumulated per step (collective_ms_exposed).  A second, extra measurement after the timed region overlaps the
-    # collective of pass k (RCCL's own stream) with the projection of pass k+1 in a second buffer: what a job that
-    # streams many scenes would see; it is reported under "overlapped_passes", never as `value`.
-    bufs = [(out, count)]
-    inflight = [None]
-    state = {"k": 0, "exposed_s": 0.0}
+    # Multi-GPU.  A step never overlaps passes: zero, project the rank's views, the collective, waited for -- a scene is ONE
+    # pass and pays its collective inside it.  Two arms (view_sharding.project_final_call_and_reduce):
+    #   split  the rank's LAST call is cut into two row ranges (the library gathers voxel IDs [0, h) first, then [h, n_rows)
+    #          from the same first-hit images); the rows below h, final after the first gather, are reduced on RCCL's stream
+    #          while the second gather runs.  Same bytes on the links, about half of them hidden; the cut itself costs a
+    #          second, shorter gather launch.
+    #   whole  the last call as it is, then one collective per tensor.
+    # The timed region runs the default arm (split; --no-split-collective: whole), the other arm runs after it for the same
+    # number of steps, and the line carries both (collective.arms).  collective_ms_exposed = pass - (zeroing + projection),
+    # the latter from HIP events around it.
+    state = {"exposed_s": 0.0}
     dst = 0 if a.collective == "reduce" else None
-
-    def drain(i=None):
-        for j in (range(len(bufs)) if i is None else [i]):
-            if inflight[j] is not None:
-                for w in inflight[j]:
-                    w.wait()
-                inflight[j] = None
-
-    # Inside a pass the collective can start before the projection ends: the pass's LAST call is cut into two row ranges
-    # (the library gathers voxel IDs [0, h) first, then [h, n_rows) from the same first-hit images), and the rows below h,
-    # final after the first gather, are reduced on RCCL's stream while the second gather runs.  Same bytes on the links, about
-    # half of them hidden; the split itself costs a second, shorter gather launch (measured through --rehearse-dist).
-    split = dist is not None and pipeline and not a.no_split_collective and n_rows > 2
-    h_rows = (n_rows // 2 + 63) & ~63 if split else 0
+    h_rows = split_point(n_rows) if dist is not None else 0
+    default_split = dist is not None and not a.no_split_collective and h_rows > 0
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def step():
-        o, c = bufs[0]
+    def step_dist(split_arm):
         t_a = time.perf_counter()
         ev_a.record()
-        c.zero_()
-        o.zero_()
+        agg.reset()
         last = len(calls) - 1
-        for ci in range(last if split else len(calls)):
-            one_call(ci, o=o, c=c)
-        if split:
-            ws.set_row_range(0, h_rows)
-            one_call(last, o=o, c=c)
-            works = reduce_partials(dist, [o[:h_rows]], dst=dst, async_op=True)      # waits for the first gather only
-            ws.set_row_range(h_rows, n_rows)
-            one_call(last, o=o, c=c, gather_only=True)
-            ws.set_row_range()
-            ev_b.record()                                                            # projection done
-            works += reduce_partials(dist, [o[h_rows:], c], dst=dst, async_op=True)
-            for w in works:
-                w.wait()
-            torch.cuda.synchronize(dev)
-            state["exposed_s"] += (time.perf_counter() - t_a) - ev_a.elapsed_time(ev_b) * 1e-3
-        elif dist is not None:
-            torch.cuda.synchronize(dev)
-            t_proj = time.perf_counter()
-            reduce_partials(dist, [o, c], dst=dst)
-            torch.cuda.synchronize(dev)
-            state["exposed_s"] += time.perf_counter() - t_proj
-        state["k"] += 1
+        for ci in range(last):
+            slot, vs = calls[ci]
+            agg.add_views(feats[0, slot:slot + len(vs)], c2ws[ci], intr4)
+        slot, vs = calls[last]
+        agg.add_final_views(feats[0, slot:slot + len(vs)], c2ws[last], intr4, dst=dst, split=split_arm, on_projected=ev_b.record)
+        torch.cuda.synchronize(dev)
+        state["exposed_s"] += (time.perf_counter() - t_a) - ev_a.elapsed_time(ev_b) * 1e-3
 
-    def step_overlapped():
-        i = state["k"] % len(bufs)
-        state["k"] += 1
-        o, c = bufs[i]
-        drain(i)
-        c.zero_()
-        o.zero_()
+    def step():
+        if dist is not None:
+            return step_dist(default_split)
+        count.zero_()
+        out.zero_()
         for ci in range(len(calls)):
-            one_call(ci, o=o, c=c)
-        inflight[i] = reduce_partials(dist, [o, c], dst=dst, async_op=True)
+            one_call(ci)
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px, heavy_px = 0, 0, 0, {}, 0, 0
@@ -735,15 +790,17 @@ def main():
     dt = time.perf_counter() - t0
     voxproj_host.workspace_status(ws, dev)
     prof = voxproj_host.profile_read()
+    voxproj_host.profile_enable(False)
     exposed_ms = state["exposed_s"] / max(1, a.steps) * 1e3
     reduced = {}      # checksums of the scene for the line (compared across runs by tests/test_gpu_bench_contract.py)
-    if dist is None and not os.environ.get("VOXPROJ_BENCH_NOVERIFY"):
+    verify = not os.environ.get("VOXPROJ_BENCH_NOVERIFY")
+    if dist is None and verify:
         # the timed passes must have produced the same result as the plain pre-pass
         assert int(count.sum().item()) == hit_px, "hit-count total changed between the pre-pass and the timed steps"
         assert ((out.double().sum(0) - ref_checksum).abs() <= 1e-6 * ref_abs + 1e-9).all(), "feature sums changed"
-        last = voxproj_host.counters(ws, dev)
+    if verify:
+        last = voxproj_host.counters(ws if agg is None else agg.ws, dev)
         assert last["bad_id"] == 0 and last["box_miss"] == 0, last
-    voxproj_host.profile_enable(False)
     if dist is None:
         # one more pass timed exactly like the placement tries (after the timed region; diagnostic only)
         for rep in range(2):
@@ -754,43 +811,48 @@ def main():
             voxproj_host.workspace_status(ws, dev)
             torch.cuda.synchronize(dev)
             placement["ms_per_pass_after_timed_region"] = round((time.perf_counter() - t1) * 1e3, 3)
-    if dist is not None and not os.environ.get("VOXPROJ_BENCH_NOVERIFY"):
-        # the buffer reduced last holds the whole scene (on rank 0 after a reduce, everywhere after an all-reduce):
-        # its hit counts must add up EXACTLY to the ranks' own (pre-pass) totals, and its feature sums, channel by
-        # channel, to the sum of the ranks' pre-pass checksums (float64) within fp32 summation rounding
+        reduced = {"checksum": float(ref_checksum.sum().item()), "checksum_abs": float(ref_abs.sum().item())}
+
+    def verify_reduced():
+        # the aggregator's buffers hold the whole scene (on rank 0 after a reduce, everywhere after an all-reduce): the hit
+        # counts must add up EXACTLY to the ranks' own (pre-pass) totals, and the feature sums, channel by channel, to the sum
+        # of the ranks' pre-pass checksums (float64) within fp32 summation rounding
         t = torch.tensor([hit_px], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         chk = torch.stack([ref_checksum, ref_abs])
         dist.all_reduce(chk)
-        last_o, last_c = bufs[0]
         if rank == 0 or a.collective == "allreduce":
-            assert int(last_c.sum().item()) == int(t.item()), "reduced hit counts do not add up to the ranks' totals"
-            assert ((last_o.double().sum(0) - chk[0]).abs() <= 1e-6 * chk[1] + 1e-9).all(), \
+            assert int(agg.count.sum().item()) == int(t.item()), "reduced hit counts do not add up to the ranks' totals"
+            assert ((agg.sum32.double().sum(0) - chk[0]).abs() <= 1e-6 * chk[1] + 1e-9).all(), \
                 "reduced feature sums differ from the sum of the ranks' single-rank results"
-            reduced = {"reduced_hit_pixels": int(last_c.sum().item()), "reduced_checksum": float(last_o.double().sum().item())}
-    overlapped = None
-    if dist is None:
-        reduced = {"checksum": float(ref_checksum.sum().item()), "checksum_abs": float(ref_abs.sum().item())}
+            assert agg.n_seen == n_views
+            return {"reduced_hit_pixels": int(agg.count.sum().item()), "reduced_checksum": float(agg.sum32.double().sum().item())}
+        return {}
+
+    arms = None
     if dist is not None:
+        if verify:
+            reduced = verify_reduced()
         t = torch.tensor([dt, exposed_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, exposed_ms = float(t[0].item()), float(t[1].item())
-        if not a.no_overlap_reduce:
-            # extra: passes overlapped with each other's collectives (two output buffers); every reduction is waited for
-            # before its buffer is reused and before the clock stops
-            bufs.append((resident((n_rows, C), torch.float32, "output_rows_2").zero_(), resident((n_rows,), torch.int32, "hit_counts_2").zero_()))
-            inflight.append(None)
-            step_overlapped()
-            drain()
+        name = {True: "split", False: "whole"}
+        arms = {name[default_split]: {"ms_per_step": round(dt / a.steps * 1e3, 3), "collective_ms_exposed": round(exposed_ms, 3)}}
+        if not a.no_other_arm and h_rows > 0:
+            # the other arm, same number of steps, bracketed the same way (never the headline)
+            state["exposed_s"] = 0.0
             barrier()
             t1 = time.perf_counter()
             for _ in range(a.steps):
-                step_overlapped()
-            drain()
+                step_dist(not default_split)
             barrier()
-            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            t = torch.tensor([time.perf_counter() - t1, state["exposed_s"] / max(1, a.steps) * 1e3], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            overlapped = float(t.item()) / a.steps
+            arms[name[not default_split]] = {"ms_per_step": round(float(t[0].item()) / a.steps * 1e3, 3),
+                                             "collective_ms_exposed": round(float(t[1].item()), 3)}
+            if verify:
+                assert verify_reduced() == reduced, "the two collective arms left different scenes"
+    split = default_split
 
     algo_local = hit_px * C * esize + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
     if dist is not None:
@@ -810,7 +872,7 @@ def main():
         algo_step = algo_local      # summed over ranks
         res = {
             "metric": "Mvoxel-views/sec", "value": round(value, 3), "unit": "Mvoxel-views/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+            "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if a.dtype == "f32" else "f32 accumulate, f16 feature maps",
             "data": "synthetic",
@@ -829,17 +891,17 @@ def main():
                                   "overlapped": pipeline},
             "pool_placement": placement, "device": device_info(dev), **reduced,
             **({"collective": {"op": "reduce to rank 0" if a.collective == "reduce" else "all-reduce", "backend": a.dist_backend,
-                               "bytes_per_rank": n_rows * C * 4 + n_rows * 4,
+                               "through": "VoxelFeatureAggregator.add_views / add_final_views (aggregate_voxel_features_onthefly.py, fast mode)",
+                               "bytes_per_rank": n_rows * C * 4 + 2 * n_rows * 4,
                                "collective_ms_exposed": round(exposed_ms, 3),
                                "projection_ms_per_step": round(ms_step - exposed_ms, 3),
+                               "timed_arm": "split" if split else "whole", "arms": arms,
                                "split": ({"rows_reduced_under_the_last_gather": h_rows, "of": n_rows} if split else None),
-                               "note": "max over ranks; the headline value includes it (no overlap between passes" +
-                                       ("; the pass's last call is cut into two row ranges, the first half's rows are reduced under "
-                                        "the second half's gather: collective_ms_exposed = pass - projection" if split else "") + ")"},
-                "overlapped_passes": (None if overlapped is None else
-                                      {"ms_per_step": round(overlapped * 1e3, 3), "value": round(n_vox * n_views / overlapped / 1e6, 3),
-                                       "what": "extra: collective of pass k overlapped with the projection of pass k+1 (two output "
-                                               "buffers), what a job streaming many scenes sees; never the headline"})} if dist is not None else {}),
+                               "note": "max over ranks; the headline value includes the collective (no overlap between passes); "
+                                       "collective_ms_exposed = pass - (zeroing + projection), the latter from HIP events.  split: the "
+                                       "rank's last call is cut into two row ranges and the first half's sums are reduced under the "
+                                       "second half's gather; whole: the call as it is, then the collectives.  The arm that is not "
+                                       "timed runs after the timed region, same number of steps"}} if dist is not None else {}),
             "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "heavy_pixels_per_step": heavy_px, "max_pixels_per_voxel_call": max_px,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -850,7 +912,7 @@ def main():
                          "level": (None if stream_gbs <= 0 else "fast" if ach / stream_gbs >= 0.98 else "mid" if ach / stream_gbs >= 0.93 else "slow"),
                          "traffic": (int(pmc_traffic(a.workload, chunk, a.dtype) * len(my_views) / len(calls))
                                      if (not a.views and world == 1 and pmc_traffic(a.workload, chunk, a.dtype)) else None),
-                         "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this build, rescaled to this "
+                         "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc passes of this build, rescaled to this "
                                            "run's views per launch; null when the kernel sources changed since) -- not measured in this run",
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }

@@ -38,23 +38,39 @@ def test_bench_line_single_gpu():
     assert d["box_miss_voxels"] == 0
 
 
-def test_bench_two_ranks_gloo_rehearsal():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
-                        "--single-device"], capture_output=True, text=True, timeout=600, env=env)
+def _no_launcher_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_two_ranks_gloo_rehearsal_started_by_bench_itself():
+    """`python bench.py --gpus 2` with NO launcher: the parent starts the two ranks as a child torchrun before touching the GPU
+    and relays rank 0's line.  gloo + --single-device rehearse the multi-rank step on the one GPU of the box: the step runs
+    through VoxelFeatureAggregator.add_views / add_final_views, both collective arms are in the line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1",
+                        "--dist-backend", "gloo", "--single-device"], capture_output=True, text=True, timeout=600, env=_no_launcher_env())
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
-    # north_star's collective is the default, named in the line; the headline pays it exposed, the overlapped figure is extra
+    # north_star's collective is the default, named in the line; the headline pays it inside the pass
     assert "all-reduce" in d["config"]["parallelism"] and d["collective"]["op"] == "all-reduce"
     assert 0 < d["collective"]["collective_ms_exposed"] < d["ms_per_step"]
-    assert d["overlapped_passes"]["value"] > 0
-    assert d["hit_pixels_per_step"] > 0 and d["value"] > 0
+    assert d["hit_pixels_per_step"] > 0 and d["value"] > 0 and d["reduced_hit_pixels"] > 0
     # the pass's last call is cut into two row ranges; the first half's rows are reduced under the second half's gather
     sp = d["collective"]["split"]
     assert 0 < sp["rows_reduced_under_the_last_gather"] < sp["of"] == 10001
+    arms = d["collective"]["arms"]
+    assert d["collective"]["timed_arm"] == "split" and set(arms) == {"split", "whole"}
+    assert arms["split"]["ms_per_step"] == d["ms_per_step"] and arms["whole"]["ms_per_step"] > 0
+    assert "VoxelFeatureAggregator" in d["collective"]["through"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    # one GPU on the box: `--gpus 2` over RCCL must fail loudly, never run on one GPU and print "n_gpus": 1
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "S0"], capture_output=True, text=True,
+                       timeout=300, env=_no_launcher_env())
+    assert r.returncode != 0 and "visible GPU" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_two_ranks_allreduce_variant():
@@ -62,12 +78,12 @@ def test_bench_two_ranks_allreduce_variant():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29535", os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
-                        "--single-device", "--collective", "reduce", "--no-overlap-reduce", "--no-split-collective"],
+                        "--single-device", "--collective", "reduce", "--no-other-arm", "--no-split-collective"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]          # bench verifies reduced counts exactly and sums against the ranks' own
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and "reduce to rank 0" in d["config"]["parallelism"] and d["overlapped_passes"] is None
-    assert d["collective"]["split"] is None
+    assert d["n_gpus"] == 2 and "reduce to rank 0" in d["config"]["parallelism"]
+    assert d["collective"]["split"] is None and d["collective"]["timed_arm"] == "whole" and set(d["collective"]["arms"]) == {"whole"}
 
 
 def test_bench_two_ranks_at_the_r2_shape():
@@ -84,12 +100,12 @@ def test_bench_two_ranks_at_the_r2_shape():
     one = _last_json(r1.stdout)
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                          "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
-                         "--gpus", "2", "--dist-backend", "gloo", "--single-device", "--no-overlap-reduce"] + common,
+                         "--gpus", "2", "--dist-backend", "gloo", "--single-device"] + common,
                         capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr[-3000:]
     two = _last_json(r2.stdout)
     assert two["n_gpus"] == 2 and two["config"]["workload"].startswith("R2: 200000 voxels x 32 views x 968x548x512")
-    assert two["collective"]["op"] == "all-reduce" and two["collective"]["bytes_per_rank"] == 200001 * 512 * 4 + 200001 * 4
+    assert two["collective"]["op"] == "all-reduce" and two["collective"]["bytes_per_rank"] == 200001 * 512 * 4 + 2 * 200001 * 4
     # the scene the two ranks reduced IS the scene one rank projects: hit pixels exactly, channel checksum to fp32 rounding
     assert two["reduced_hit_pixels"] == one["hit_pixels_per_step"]
     assert abs(two["reduced_checksum"] - one["checksum"]) <= 1e-6 * one["checksum_abs"]
@@ -166,8 +182,8 @@ def test_job_mode_overlap_survives_a_single_hardware_queue():
 
 
 def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
-    """`--rehearse-dist`: the N > 1 control flow of bench.py (collective inside the pass, exact verification of the reduced
-    counts, overlapped passes) with backend nccl = RCCL and ONE rank -- the only way RCCL can run this code on a one-GPU
+    """`--rehearse-dist`: the N > 1 control flow of bench.py (the aggregator's add_views / add_final_views, collective inside
+    the pass, exact verification of the reduced counts, both collective arms) with backend nccl = RCCL and ONE rank -- the only way RCCL can run this code on a one-GPU
     box.  RCCL initialised before the first pipelined call used to cost the march/gather overlap (63 vs 54 ms per R2
     pass): asserted here on the R1 workload."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "3", "--warmup", "1",
@@ -176,7 +192,7 @@ def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["collective"]["backend"] == "nccl" and d["collective"]["op"] == "all-reduce"
-    assert d["collective"]["collective_ms_exposed"] >= 0 and d["overlapped_passes"]["value"] > 0
+    assert d["collective"]["collective_ms_exposed"] >= 0 and set(d["collective"]["arms"]) == {"split", "whole"}
     assert d["reduced_hit_pixels"] == d["hit_pixels_per_step"]
     assert "rehearsal" in d["config"]["parallelism"] and "cpu_baseline" not in d
     assert _overlapped(d), (d["ms_per_step"], d["phase_ms_per_step"])

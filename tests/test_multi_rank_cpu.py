@@ -47,6 +47,27 @@ def _filled_aggregator(oracle, s, feats, views):
     return agg
 
 
+def _final_call_stand_in(oracle, agg, s, feats, log):
+    """Stands in for the projector inside add_final_views (there is no GPU here): `feats` carries VIEW INDICES; the call
+    accumulates the oracle's sums of those views for the voxel IDs of the row range now set on the aggregator's workspace --
+    what vp_project_features / VP_FLAG_GATHER_ONLY leave in {sum32, count, views}."""
+    import voxproj_host as vh
+    n_rows = agg.n_rows
+
+    def project(view_ids, vmi, intr, gather_only=False):
+        lo = agg.ws.options.get(vh.VP_OPT_ROW_BEGIN, 0)
+        hi = agg.ws.options.get(vh.VP_OPT_ROW_END, n_rows)
+        log.append((bool(gather_only), lo, hi))
+        count, sums, nviews = np.zeros(n_rows, np.int32), np.zeros((n_rows, 8), np.float32), np.zeros(n_rows, np.int32)
+        _project(oracle, s, feats, [int(v) for v in view_ids], count, sums, nviews)
+        agg.sum32[lo:hi] += torch.from_numpy(sums[lo:hi])
+        agg.count[lo:hi] += torch.from_numpy(count[lo:hi])
+        agg.views[lo:hi] += torch.from_numpy(nviews[lo:hi])
+
+    agg._stage = lambda f, c, i: (f, c, i, None)
+    agg._project_fast = project
+
+
 def _worker(rank, world, port, out_path):
     for p in (ROOT, PKG):
         sys.path.insert(0, p)
@@ -67,6 +88,25 @@ def _worker(rank, world, port, out_path):
             res[name] = dict(sums=agg.sum32.numpy().copy(), count=agg.count.numpy().copy(), nviews=agg.views.numpy().copy(),
                              avg=r["avg_feats"].numpy(), coords=r["voxel_coords"].numpy(), xyz=r["xyz"].numpy(),
                              hit_count=r["hit_count"].numpy())
+    # The split form the entry point ships (add_final_views -> view_sharding.project_final_call_and_reduce): all views but the
+    # rank's last two as ordinary calls, the last two as the final call, cut at split_point(n_rows); then the unsplit arm.
+    from view_sharding import split_point
+    import voxproj_host as vh
+    for name, split in (("split", True), ("unsplit", False)):
+        agg = _filled_aggregator(oracle, s, feats, mine[:-2])
+        log = []
+        _final_call_stand_in(oracle, agg, s, feats, log)
+        h = agg.add_final_views(torch.tensor(mine[-2:]), torch.zeros(2, 4, 4), torch.zeros(4), dst=None, split=split)
+        n_rows = s.n_vox + 1
+        assert h == (split_point(n_rows) if split else 0) and 0 <= h < n_rows and h % 64 == 0
+        assert log == ([(False, 0, h), (True, h, n_rows)] if split else [(False, 0, n_rows)]), log
+        assert vh.VP_OPT_ROW_BEGIN not in agg.ws.options and vh.VP_OPT_ROW_END not in agg.ws.options     # range reset
+        assert agg.n_seen == 7
+        r = agg.result()
+        res[name] = dict(sums=agg.sum32.numpy().copy(), count=agg.count.numpy().copy(), nviews=agg.views.numpy().copy(),
+                         avg=r["avg_feats"].numpy(), coords=r["voxel_coords"].numpy(), xyz=r["xyz"].numpy(),
+                         hit_count=r["hit_count"].numpy())
+    assert res["split"]["sums"].tobytes() == res["unsplit"]["sums"].tobytes()      # the cut changes no bit of the reduced scene
     if rank == 1:                                              # after an all-reduce every rank holds the scene
         np.savez(out_path + ".rank1.npz", **{k: v for k, v in res["all"].items()})
     if rank == 0:
@@ -89,7 +129,7 @@ def test_two_rank_view_sharding_equals_single_rank(tmp_path, oracle_mod):
     r = single.result()
     count, sums, nviews = single.count.numpy(), single.sum32.numpy(), single.views.numpy()
     assert count.sum() > 5000
-    for name in ("all", "root"):
+    for name in ("all", "root", "split", "unsplit"):
         assert np.array_equal(got[f"{name}_count"], count) and np.array_equal(got[f"{name}_nviews"], nviews)
         np.testing.assert_allclose(got[f"{name}_sums"], sums, rtol=1e-5, atol=1e-6)
         # the files' rows: same voxels in the same order, same coordinates, fp16 means equal up to the fp32 summation order
