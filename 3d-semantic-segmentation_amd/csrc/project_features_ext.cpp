@@ -153,7 +153,7 @@ void project_features_cuda(at::Tensor encoded_2d_features, at::Tensor occupancy_
     const int flags = VP_FLAG_SYNC | (reuse ? VP_FLAG_REUSE_ACCEL : (cache ? VP_FLAG_VERIFY_ACCEL : 0)) |
                       (g_exact_march.load() ? VP_FLAG_EXACT_MARCH : 0);
 
-    // blocks until the device is done, GIL held, like the reference (kernel.cu:454-457)
+    // blocks until the device is done, like the reference (kernel.cu:454-457); the binding below releases the GIL around it
     const int rc = vp_project_features(encoded_2d_features.data_ptr<float>(), occupancy_3D.data_ptr<int64_t>(),
                                        viewMatrixInv.data_ptr<float>(), intrinsicParams.data_ptr<float>(),
                                        opts_cpu.data_ptr<float>(), mapping2dto3d_num.data_ptr<int32_t>(),

@@ -96,6 +96,8 @@ size_t vp_workspace_bytes(int B, int V, int H, int W, int C, int dimz, int dimy,
     return make_layout(B, V, H, W, n_rows, dimz, dimy, dimx).total;
 }
 
+static int workspace_status_impl(void *workspace, void *stream_, bool drain_all);
+
 static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, const float *vmi, const float *intr,
                         const float *opts_host, int32_t *count, float *out, int32_t *views_hit,
                         const float *grid_origin_host, float voxel_size,
@@ -106,6 +108,11 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         return fail(VP_EINVAL, "fp16 feature maps need C %% 8 == 0 and 16-byte aligned feats/out");
     if (!feats || !occ || !vmi || !intr || !opts_host || !count || !out || !grid_origin_host || !workspace)
         return fail(VP_EINVAL, "null pointer argument");
+    // What VP_FLAG_GATHER_ONLY and vp_copy_hit_image rely on (first-hit images of the last call, its arguments) is valid only
+    // once a call has queued all of its launches: withdrawn when a call fails -- refused arguments, refused flag, HIP error --
+    // so that a later gather-only call cannot match the call before the failed one
+    WsState *st = ws_state(workspace, true);
+    struct HitGuard { WsState *st; bool keep; ~HitGuard() { if (!keep) st->has_hit = false; } } hit_guard{st, false};
     if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || C <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0 || n_rows <= 0)
         return fail(VP_EINVAL, "non-positive dimension");
     if ((long long)B * V > 65535) return fail(VP_EINVAL, "B*V = %lld exceeds 65535", (long long)B * V);
@@ -133,7 +140,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // buffer set and streams: plain calls use set 0 on the caller's stream only; pipelined calls alternate sets
     // and run phase 1 on the side stream
     const bool pipe = (flags & VP_FLAG_PIPELINE) != 0;
-    WsState *st = ws_state(workspace, true);
     PipeState *ps = &st->pipe;
     if (pipe && !pipe_open(*ps)) return fail(VP_EHIP, "could not create the side stream / events for VP_FLAG_PIPELINE");
     // VP_FLAG_GATHER_ONLY: phase 2 once more, on another row range, from what the previous call's phase 1 left in ITS
@@ -142,12 +148,16 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (gather_only) {
         if (!st->has_hit || st->last_feats != (const void *)feats || st->last_f16 != feats_f16 || st->last_B != B || st->last_V != V ||
             st->last_H != H || st->last_W != W || st->last_C != C || st->B != B || st->dimz != dimz || st->dimy != dimy ||
-            st->dimx != dimx || st->n_rows != n_rows)
-            return fail(VP_EINVAL, "VP_FLAG_GATHER_ONLY repeats phase 2 of the previous call on this workspace: there is none, or "
-                                   "its feature maps / shapes differ from this call's");
+            st->dimx != dimx || st->n_rows != n_rows || st->last_out != (const void *)out || st->last_count != (const void *)count ||
+            st->last_vmi != (const void *)vmi)
+            return fail(VP_EINVAL, "VP_FLAG_GATHER_ONLY repeats phase 2 of the previous call on this workspace: there is none (or it "
+                                   "failed), or its feature maps / poses / outputs / shapes differ from this call's");
         if (st->opt_row_begin < 0 && st->opt_row_end < 0)
             return fail(VP_EINVAL, "VP_FLAG_GATHER_ONLY without a row range (VP_OPT_ROW_BEGIN / VP_OPT_ROW_END) would gather every row twice");
+        if (!st->last_ranged)
+            return fail(VP_EINVAL, "VP_FLAG_GATHER_ONLY after a call that had no row range: that call gathered every row already");
     }
+
     int q = 0;
     hipStream_t s1 = s0;
     if (gather_only) {
@@ -172,8 +182,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     ViewEntry *viewtab = (ViewEntry *)(ws + l.viewtab[q]);
     int *hit = (int *)(ws + l.hit[q]);
     int *status0 = (int *)(ws + l.status[0]);      // header + sticky words live in the block of set 0
-    st->has_hit = true;
-    st->hit_off = l.hit[q];
 
     // Occupancy-derived tables: rebuilt unless the caller vouches for them (VP_FLAG_REUSE_ACCEL) or asks for a
     // check (VP_FLAG_VERIFY_ACCEL, blocking calls only): then the grid is compared with the copy the tables were
@@ -249,8 +257,9 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // set q was last used two calls ago: its gather must be over before phase 1 overwrites hit/cnt
         if (ps->used[q]) VP_HIP(hipStreamWaitEvent(s1, ps->call_done[q], 0));
     }
-    // Row range of phase 2 (VP_OPT_ROW_BEGIN / _END).  While one is set no voxel takes the workgroup path: the heavy list
-    // is the march's, i.e. the whole call's, and the two gathers of a split call must not both work through it.
+    // Row range of phase 2 (VP_OPT_ROW_BEGIN / _END).  The heavy list is the march's, i.e. the whole call's: the workgroup
+    // role of a ranged gather skips the listed IDs outside its range, so the gathers of a split call share the list without
+    // summing a voxel twice -- and every voxel is summed by the same role (and so to the same bits) as in the unsplit call.
     const bool ranged = rec.opt_row_begin >= 0 || rec.opt_row_end >= 0;
     const long long row_lo = std::max<long long>(1, rec.opt_row_begin);
     const long long row_hi = rec.opt_row_end < 0 ? (long long)n_rows : std::min<long long>(rec.opt_row_end, (long long)n_rows);
@@ -258,7 +267,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // ---- phase 1 (on s1) ----
     int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
     if (rec.opt_heavy_t > 0) heavy_t = (int)std::min<long long>(rec.opt_heavy_t, 2147483647ll);   // VP_OPT_HEAVY_THRESHOLD
-    if ((flags & VP_FLAG_SERIAL_SUMS) || ranged || gather_only) heavy_t = 2147483647;
+    if (flags & VP_FLAG_SERIAL_SUMS) heavy_t = 2147483647;
+    if (gather_only) heavy_t = st->last_heavy_t;       // the threshold the march of the previous call enlisted heavy voxels with
 #ifdef VP_DIAG
     if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
 #endif
@@ -303,7 +313,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
             // 6 and 4 are worse (profiles/r03_march_occupancy_cap_sweep.log).
             const size_t row_bytes = size_t(C) * (feats_f16 ? 2 : 4);
             size_t lds_req = beside_gather ? (row_bytes <= 1024 ? 30 : 41) * 1024 : 0;
-            if (rec.opt_march_lds_kb >= 0) lds_req = size_t(std::min<long long>(rec.opt_march_lds_kb, 160)) * 1024;   // VP_OPT_MARCH_LDS_KB
+            if (rec.opt_march_lds_kb >= 0) lds_req = size_t(std::min<long long>(rec.opt_march_lds_kb, 64)) * 1024;   // VP_OPT_MARCH_LDS_KB
             hipLaunchKernelGGL(k_first_hit<1>, grid, dim3(256), lds_req, s1, fa, p);
         }
         // the gather's work list: touched voxels by size class, largest first (needs the finished histogram); its trailing
@@ -318,7 +328,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // ---- phase 2 ----
     GatherArgs g;
     g.feats = feats; g.hit = hit; g.viewtab = viewtab; g.intr = intr; g.cell_of_id = cell_of_id;
-    g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + (gather_only ? ST_ZERO : ST_NHEAVY);
+    g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
+    g.row_lo = (int)row_lo; g.row_hi = (int)row_hi;
     g.work = work; g.work_n = status + ST_WORK0;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
@@ -353,10 +364,13 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     } else if (!gather_only) {
         ps->last_q = 0;
     }
-    st->last_B = B; st->last_V = V; st->last_H = H; st->last_W = W; st->last_C = C; st->last_q = q;
-    st->last_f16 = feats_f16; st->last_feats = (const void *)feats;
     VP_HIP(hipGetLastError());
-    if (flags & VP_FLAG_SYNC) return vp_workspace_status(workspace, stream_);
+    st->last_B = B; st->last_V = V; st->last_H = H; st->last_W = W; st->last_C = C; st->last_q = q;
+    st->last_f16 = feats_f16; st->last_feats = (const void *)feats; st->last_out = (const void *)out; st->last_count = (const void *)count;
+    st->last_vmi = (const void *)vmi; st->last_ranged = ranged; st->last_heavy_t = heavy_t;
+    st->has_hit = true; st->hit_off = l.hit[q];
+    hit_guard.keep = true;
+    if (flags & VP_FLAG_SYNC) return workspace_status_impl(workspace, stream_, true);
     return VP_OK;
 }
 
@@ -413,7 +427,10 @@ int vp_stream_read(const float *src, int64_t n_floats, float *sink, void *stream
     return VP_OK;
 }
 
-int vp_workspace_status(void *workspace, void *stream_)
+// drain_all: report the highest-priority pending condition, name the others in the message and clear ALL of them (the end of
+// a VP_FLAG_SYNC call: every pending error belongs to this call or to asynchronous ones before it, and a word left behind
+// would fail the next, valid blocking call); otherwise ONE condition per read, only the reported word is cleared.
+static int workspace_status_impl(void *workspace, void *stream_, bool drain_all)
 {
     if (!workspace) return fail(VP_EINVAL, "null workspace");
     static_assert(ST_WORDS * sizeof(int) == 256, "status block is one 256-byte slot");
@@ -423,29 +440,40 @@ int vp_workspace_status(void *workspace, void *stream_)
     if (rc != VP_OK) return rc;
     WsState *rec = ws_state(workspace, false);
     if (!rec || !rec->opened) return VP_OK;   // no call has run on this workspace yet
-    // the sticky words collect the errors of EVERY call since the last vp_workspace_status (the per-call words of a
-    // buffer set are cleared when the set is reused two pipelined calls later).  ONE condition is reported per read, and only
-    // the word that is reported is cleared: the others stay pending for the next read.
+    // the sticky words mean something only in memory that carries this record's header: anything else (freed and handed out
+    // again, overwritten, and no call has looked at it since) reads back as garbage -- the next call's k_zero_call reports it
+    if ((unsigned)st[ST_HDR_MAGIC] != WS_MAGIC || (unsigned)st[ST_HDR_GEN] != rec->gen) return VP_OK;
+    // the sticky words collect the errors of EVERY call since the last read (the per-call words of a buffer set are cleared
+    // when the set is reused two pipelined calls later)
     const int stale = st[ST_STICKY_STALE], stuck = st[ST_STICKY_STUCK], badid = st[ST_STICKY_BADID];
     const int word = stale ? ST_STICKY_STALE : stuck ? ST_STICKY_STUCK : badid ? ST_STICKY_BADID : -1;
     if (word >= 0) {
-        VP_HIP(hipMemsetAsync((int *)workspace + word, 0, sizeof(int), (hipStream_t)stream_));
+        if (drain_all) {
+            static_assert(ST_STICKY_STALE + 2 == ST_STICKY_STUCK, "the three sticky words are contiguous");
+            VP_HIP(hipMemsetAsync((int *)workspace + ST_STICKY_STALE, 0, 3 * sizeof(int), (hipStream_t)stream_));
+        } else {
+            VP_HIP(hipMemsetAsync((int *)workspace + word, 0, sizeof(int), (hipStream_t)stream_));
+        }
         VP_HIP(hipStreamSynchronize((hipStream_t)stream_));
     }
+    const char *also = !drain_all ? "" : (word == ST_STICKY_STALE && (stuck || badid)) ? " (also pending, now cleared: stuck rays and/or out-of-range IDs)"
+                                        : (word == ST_STICKY_STUCK && badid) ? " (also: a ray hit an occupancy ID outside [1, n_rows))" : "";
     if (stale) {
         rec->builds = 0;        // whatever tables the memory held are gone: VP_FLAG_REUSE_ACCEL is refused until a rebuild
         rec->copy_valid = false;
         return fail(VP_EINVAL, "VP_FLAG_REUSE_ACCEL, but the workspace memory no longer holds the tables this library built in it "
                                "(freed and handed out again without vp_workspace_release, or overwritten): those calls did no "
-                               "work; call once without the flag");
+                               "work; call once without the flag%s", also);
     }
     if (stuck)
         return fail(VP_EINVAL, "rayIncrement is too small to advance a float32 ray parameter near depthMax: the reference "
-                               "loop would never terminate (those rays were skipped, outputs are incomplete)");
+                               "loop would never terminate (those rays were skipped, outputs are incomplete)%s", also);
     if (badid)
         return fail(VP_EBADID, "a ray hit an occupancy ID outside [1, n_rows): outputs are too small for the grid's IDs");
     return VP_OK;
 }
+
+int vp_workspace_status(void *workspace, void *stream_) { return workspace_status_impl(workspace, stream_, false); }
 
 int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream_)
 {
@@ -671,7 +699,11 @@ int vp_workspace_set_option(void *workspace, int option, long long value)
     WsState *rec = ws_state(workspace, true);
     switch (option) {
     case VP_OPT_HEAVY_THRESHOLD: rec->opt_heavy_t = value > 0 ? value : -1; return VP_OK;
-    case VP_OPT_MARCH_LDS_KB:    rec->opt_march_lds_kb = value >= 0 ? value : -1; return VP_OK;
+    case VP_OPT_MARCH_LDS_KB:
+        // the reservation is dynamic LDS of k_first_hit, whose limit without a function attribute is 64 KiB: a larger value
+        // would fail every launch on this workspace with a generic HIP error, surfacing (pipelined) only calls later
+        if (value > 64) return fail(VP_EINVAL, "VP_OPT_MARCH_LDS_KB = %lld: the march's dynamic-LDS reservation is limited to 64 KiB (0 .. 64; < 0 = default)", value);
+        rec->opt_march_lds_kb = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ROW_BEGIN:       rec->opt_row_begin = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ROW_END:         rec->opt_row_end = value >= 0 ? value : -1; return VP_OK;
     default: return fail(VP_EINVAL, "unknown workspace option %d", option);

@@ -102,8 +102,9 @@ struct WsState {
     long long opt_row_begin = -1, opt_row_end = -1;     // VP_OPT_ROW_BEGIN / _END: phase 2 gathers IDs in [begin, end)
     // arguments of the last vp_project_features call (VP_FLAG_GATHER_ONLY repeats its phase 2 on another row range)
     int last_B = 0, last_V = 0, last_H = 0, last_W = 0, last_C = 0, last_q = 0;
-    bool last_f16 = false;
-    const void *last_feats = nullptr;
+    bool last_f16 = false, last_ranged = false;
+    int last_heavy_t = 0;
+    const void *last_feats = nullptr, *last_out = nullptr, *last_count = nullptr, *last_vmi = nullptr;
     // first-hit image of the last call (vp_copy_hit_image)
     bool has_hit = false;
     size_t hit_off = 0;
@@ -192,7 +193,7 @@ struct Params {
 // so an error raised by pipelined call j is still there when the job finally asks, however many calls later.
 // ST_HDR_*: the workspace header (set 0 only): magic, the generation of the record that initialised this memory, the key
 // of the tables it holds (0 while none are sealed) -- written by k_ws_open / k_ws_seal, compared by every call's k_zero_call.
-enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_ZERO = 3 /* never written: "no heavy voxels" for a row-range gather */, ST_STUCK = 4, ST_OCCDIFF = 5, ST_STALE = 6,
+enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_ZERO = 3 /* never written */, ST_STUCK = 4, ST_OCCDIFF = 5, ST_STALE = 6,
        ST_WORK0 = 16, WORK_CLASSES = 8,        // per-call: number of voxels in each size class of the gather's work list
        ST_CALL_WORDS = 32,
        ST_HDR_MAGIC = 56, ST_HDR_GEN = 57, ST_HDR_TABLES = 58,

@@ -219,6 +219,7 @@ struct GatherArgs {
     const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
     const int *n_heavy;
     int heavy_t;
+    int row_lo, row_hi;      // phase 2 of this launch covers the voxel IDs in [row_lo, row_hi) (VP_OPT_ROW_BEGIN / _END)
     int heavy_blocks;        // leading workgroups of k_gather that take the heavy voxels (0: k_gather_heavy does)
     const int *work;         // work list of this call: WORK_CLASSES arrays of n_rows voxel IDs, by size class (k_worklist)
     const int *work_n;       // voxels per class
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
         const int n_heavy = *g.n_heavy;
         for (int h = blockIdx.x; h < n_heavy; h += g.heavy_blocks) {
             const int id = g.heavy_list[h];
+            if (id < g.row_lo || id >= g.row_hi) continue;     // the list is the whole call's; the other range's gather takes it
             const int expected = g.cnt_call[id];
             if constexpr (MERGED) {
                 if (!gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, false)) {
@@ -675,6 +677,7 @@ __global__ __launch_bounds__(GW_ALONE * 64) void k_gather_heavy(GatherArgs g, Pa
     const int n_heavy = *g.n_heavy;
     for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const int id = g.heavy_list[h];
+        if (id < g.row_lo || id >= g.row_hi) continue;
         const int expected = g.cnt_call[id];
         if (!gather_voxel_block<K, VEC, U, GW_ALONE>(g, p, id, expected, part, part_found, false)) {
             if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);

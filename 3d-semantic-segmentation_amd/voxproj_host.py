@@ -263,7 +263,7 @@ def get_workspace(device):
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
                          workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False,
-                         views_hit=None, verify_accel=False, gather_only=False):
+                         views_hit=None, verify_accel=False, gather_only=False, serial_sums=False):
     """Call vp_project_features (or vp_project_features_f16 when ``feats`` is float16) on torch CUDA tensors
     (already validated by the caller).
 
@@ -280,6 +280,8 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     built from and rebuild only if it changed (VP_FLAG_VERIFY_ACCEL) -- for callers that make a new, equal
     occupancy tensor for every call.  ``gather_only``: VP_FLAG_GATHER_ONLY -- no ray-march, phase 2 of the PREVIOUS call on
     this workspace (same tensors) once more, for the row range now set with ``Workspace.set_row_range``.
+    ``serial_sums``: VP_FLAG_SERIAL_SUMS -- every voxel summed by one wavefront in (b, v, y, x) order, the oracle's bits (no
+    workgroup path for voxels with very many pixels).
     """
     import torch
     B, V, H, W, C = feats.shape
@@ -297,7 +299,7 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     flags = ((VP_FLAG_SYNC if (sync and not pipeline) else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
              | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0)
              | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel and ACCEL_CACHE) else 0)
-             | (VP_FLAG_GATHER_ONLY if gather_only else 0))
+             | (VP_FLAG_GATHER_ONLY if gather_only else 0) | (VP_FLAG_SERIAL_SUMS if serial_sums else 0))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream

@@ -38,7 +38,9 @@ enum {
 /* flags for vp_project_features */
 enum {
     VP_FLAG_SYNC = 1,        /* block until the device work is done and report device-side errors
-                                (the reference always does: K.cu:454-457)                          */
+                                (the reference always does: K.cu:454-457).  EVERY error pending on the
+                                workspace is drained by this report: the highest-ranking one is returned, the
+                                others are named in vp_last_error, none is left to fail the next call       */
     VP_FLAG_REUSE_ACCEL = 2, /* the occupancy-derived tables in the workspace are still valid for
                                 this occupancy grid (same pointer, contents and n_rows): skip
                                 rebuilding them.  VP_EINVAL if the library has not built tables on
@@ -64,7 +66,9 @@ enum {
                                   now set with VP_OPT_ROW_BEGIN / VP_OPT_ROW_END.  Two calls -- rows [0, h), then rows [h, n_rows)
                                   with this flag -- leave exactly what one call leaves, and the rows below h are final while
                                   the second gather still runs: a multi-GPU job starts their all-reduce under it.  Runs on the
-                                  caller's stream; VP_EINVAL when no call precedes it on the workspace or its shape differs */
+                                  caller's stream; VP_EINVAL when no SUCCESSFUL call precedes it on the workspace, when that
+                                  call had no row range (it gathered every row already), or when its feature maps, poses,
+                                  outputs or shapes differ from this call's */
     VP_FLAG_VERIFY_ACCEL = 16  /* blocking calls only (ignored with VP_FLAG_PIPELINE or VP_FLAG_REUSE_ACCEL): the
                                 workspace has not been written by anyone else since the previous call on it;
                                 compare the occupancy grid with the 32-bit copy kept from the call that built
@@ -283,11 +287,13 @@ int vp_workspace_release(void *workspace);
  *                           (default 256 + 64*B*V; VP_FLAG_SERIAL_SUMS overrides it with "never")
  *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
  *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a
- *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise)
+ *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise).  Valid: 0 .. 64
+ *                           (a kernel's dynamic-LDS limit); larger values are refused with VP_EINVAL
  *   VP_OPT_ROW_BEGIN / _END phase 2 of the following calls gathers only the voxel IDs in [begin, end) (default: all rows;
  *                           value < 0 restores it).  Phase 1 is not restricted: the histogram it leaves covers every row, so
- *                           that a VP_FLAG_GATHER_ONLY call can gather the other rows from it.  While a range is set, every
- *                           voxel is summed by one wavefront in (b, v, y, x) order, as with VP_FLAG_SERIAL_SUMS
+ *                           that a VP_FLAG_GATHER_ONLY call can gather the other rows from it.  The list of heavy voxels is
+ *                           the whole call's too: each ranged gather takes the listed IDs inside its own range, so every
+ *                           voxel is summed by the same kernel role -- to the same bits -- as in the unsplit call
  */
 enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2, VP_OPT_ROW_BEGIN = 3, VP_OPT_ROW_END = 4 };
 int vp_workspace_set_option(void *workspace, int option, long long value);

@@ -23,7 +23,7 @@
  * independently written numpy twin (oracle/numpy_twin.py).  The RGB path
  * (rgb_project below) IS pinned against outputs of the reference's own
  * debug_project_colors.py run in the build container
- * (tests/golden/make_rgb_golden.py).
+ * (tests/golden/make_reference_goldens.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  Build: oracle/Makefile (gcc, -ffp-contract=off so that

@@ -73,6 +73,28 @@ def test_aggregator_parity_mode_matches_golden():
     assert r["xyz"].dtype == torch.float32 and r["xyz"].numpy().tobytes() == g["agg_xyz"].tobytes()
 
 
+def test_aggregator_parity_mode_keeps_host_poses_alive_one_view_per_call():
+    """the first add_views of a parity aggregator (and every one that flushes) used to enter its freshly staged
+    poses in the keep-alive list BEFORE the flush that empties it; the one-view calls are pipelined, so the library's side
+    stream -- which torch's allocator does not know -- could still read a pose block that the next call's staging copy had
+    already been handed.  Every view through its own add_views with a HOST pose, back to back: the poses of the call in
+    progress are held after it returns, and the file is the golden's bit for bit."""
+    from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
+    from make_oracle_goldens import S1, s1_inputs
+    g = np.load(os.path.join(HERE, "golden", "s1_oracle_golden.npz"))
+    s, feats = s1_inputs()
+    for rep in range(3):
+        agg = VoxelFeatureAggregator(torch.from_numpy(s.occ), s.grid_origin.astype(np.float64), s.voxel_size, S1["channels"], "parity", DEV)
+        f = torch.from_numpy(feats).to(DEV)
+        for v in range(feats.shape[0]):
+            agg.add_views(f[v:v + 1], torch.from_numpy(s.c2w[v:v + 1].copy()), torch.from_numpy(s.intr))
+            held = [k[0].data_ptr() for k in agg._keep]
+            assert len(held) == v + 1 and len(set(held)) == v + 1          # this call's poses included, every block distinct
+        r = agg.result()
+        assert np.array_equal(r["voxel_coords"].numpy(), g["agg_coords"]) and np.array_equal(r["hit_count"].numpy(), g["agg_hits"])
+        assert r["avg_feats"].numpy().tobytes() == g["agg_avg"].tobytes()
+
+
 def test_aggregator_fast_mode_is_the_exact_fp32_version(oracle_mod):
     from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
     from make_oracle_goldens import S1, s1_inputs

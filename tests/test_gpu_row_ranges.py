@@ -1,7 +1,8 @@
 """Row ranges of phase 2 (VP_OPT_ROW_BEGIN / _END + VP_FLAG_GATHER_ONLY): a call cut into [0, h) and [h, n_rows) leaves
-exactly what one call leaves -- the oracle's bits, since a ranged gather sums every voxel with one wavefront -- and the rows
-below h are final as soon as the first gather is over: what a multi-GPU job needs to start their all-reduce under the
-second gather.  No counterpart in the reference (single GPU, one atomicAdd per channel)."""
+exactly what one call leaves, bit for bit -- every voxel is summed by the same kernel role in both forms (one wavefront, or
+the workgroup role for voxels above the heavy threshold, whose list the ranged gathers share) -- and the rows below h are
+final as soon as the first gather is over: what a multi-GPU job needs to start their all-reduce under the second gather.
+With VP_FLAG_SERIAL_SUMS those bits are the oracle's.  No counterpart in the reference (single GPU, one atomicAdd per channel)."""
 import numpy as np
 import pytest
 import torch
@@ -53,7 +54,7 @@ def test_blocking_call_cut_into_row_ranges(oracle_mod, V, half):
     ws = voxproj_host.Workspace()
     for k in range(3):
         ws.set_row_range(cuts[k], cuts[k + 1])
-        _call(t, s, ws, count, out, sync=True, gather_only=k > 0, views_hit=views)
+        _call(t, s, ws, count, out, sync=True, gather_only=k > 0, views_hit=views, serial_sums=True)
         got_c, got_o = count.cpu().numpy(), out.cpu().numpy()
         done = cuts[k + 1]
         assert np.array_equal(got_c[:done], ref_c[:done]) and got_o[:done].tobytes() == ref_o[:done].tobytes()
@@ -67,24 +68,34 @@ def test_blocking_call_cut_into_row_ranges(oracle_mod, V, half):
     ws.release()
 
 
-def test_heavy_voxels_are_not_gathered_twice(oracle_mod):
-    """With the production threshold lowered to 6 pixels most voxels of the scene would take the workgroup path, whose list
-    is the march's -- the whole call's.  A ranged gather must not work through it in both halves."""
+@pytest.mark.parametrize("V", [3, 9])
+def test_heavy_voxels_of_a_ranged_call_take_the_workgroup_path_once(oracle_mod, V):
+    """With the production threshold lowered to 6 pixels most voxels of the scene take the workgroup path, whose list is the
+    march's -- the whole call's.  The ranged gathers share it: each takes the listed IDs inside its own range (few views: the
+    heavy voxels' own launch; many: the merged role), none is summed twice, and the result is the unsplit call's bit for bit."""
     import voxproj_host
-    dev, s, feats, t = _setup(9, 32, seed=163)
+    dev, s, feats, t = _setup(V, 32, seed=163 + V)
     n_rows = s.n_vox + 1
     ref_c, ref_o = _oracle(oracle_mod, s, feats)
-    count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 32, device=dev)
-    ws = voxproj_host.Workspace()
-    ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, 6)
-    h = n_rows // 2
-    ws.set_row_range(0, h)
-    _call(t, s, ws, count, out, sync=True)
-    assert voxproj_host.counters(ws, dev)["n_heavy"] == 0
-    ws.set_row_range(h, n_rows)
-    _call(t, s, ws, count, out, sync=True, gather_only=True)
-    assert np.array_equal(count.cpu().numpy(), ref_c) and out.cpu().numpy().tobytes() == ref_o.tobytes()
-    ws.release()
+    res = []
+    for cuts in ([0, n_rows], [0, n_rows // 3, n_rows // 2, n_rows]):
+        count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 32, device=dev)
+        ws = voxproj_host.Workspace()
+        ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, 6)
+        for k in range(len(cuts) - 1):
+            if len(cuts) > 2:
+                ws.set_row_range(cuts[k], cuts[k + 1])
+            _call(t, s, ws, count, out, sync=True, gather_only=k > 0)
+            assert voxproj_host.counters(ws, dev)["n_heavy"] > 50
+            if len(cuts) > 2:
+                done = cuts[k + 1]
+                assert np.array_equal(count.cpu().numpy()[:done], ref_c[:done]) and not count.cpu().numpy()[done:].any()
+        res.append((count.cpu().numpy(), out.cpu().numpy()))
+        ws.release()
+    assert np.array_equal(res[0][0], ref_c) and np.array_equal(res[1][0], ref_c)
+    assert res[0][1].tobytes() == res[1][1].tobytes()                       # split == whole, bit for bit
+    scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(res[0][1] - ref_o) / scale).max() <= 1e-4                # the workgroup role's fixed tree vs the serial order
 
 
 def test_job_mode_with_every_call_cut_in_two(oracle_mod):
@@ -132,5 +143,23 @@ def test_gather_only_is_refused_without_a_matching_predecessor():
     ws.set_row_range()
     _call(t, s, ws, count, out, sync=True)
     with pytest.raises(voxproj_host.VoxprojError, match="without a row range"):
+        _call(t, s, ws, count, out, sync=True, gather_only=True)
+    # a predecessor that had no row range gathered every row already
+    ws.set_row_range(0, 100)
+    with pytest.raises(voxproj_host.VoxprojError, match="had no row range"):
+        _call(t, s, ws, count, out, sync=True, gather_only=True)
+    # ... other outputs than the predecessor's
+    _call(t, s, ws, count, out, sync=True)
+    ws.set_row_range(100, n_rows)
+    with pytest.raises(voxproj_host.VoxprojError, match="repeats phase 2 of the previous call"):
+        _call(t, s, ws, count, torch.zeros_like(out), sync=True, gather_only=True)
+    # ... and a predecessor that FAILED leaves nothing to repeat (its arguments matched an older call's before)
+    ws.set_row_range(0, 100)
+    _call(t, s, ws, count, out, sync=True)
+    bad = dict(t, opts=t["opts"][:4] + [0.0])                             # rayIncrement 0: refused before any launch
+    with pytest.raises(voxproj_host.VoxprojError, match="rayIncrement"):
+        _call(bad, s, ws, count, out, sync=True)
+    ws.set_row_range(100, n_rows)
+    with pytest.raises(voxproj_host.VoxprojError, match="repeats phase 2 of the previous call"):
         _call(t, s, ws, count, out, sync=True, gather_only=True)
     ws.release()

@@ -1,6 +1,15 @@
 """Latency of the drop-in call used the way the reference uses it (debug_project_features.py:141-208): ONE view per
-blocking call at the R2 resolution, (a) the same occupancy tensor every call, (b) a fresh `.long()` copy per call as
-DPF:143 makes -- the occupancy-derived tables are then rebuilt every time.  python tools/bench_dropin.py"""
+blocking call, (a) the same occupancy tensor every call, (b) a fresh `.long()` copy per call as DPF:143 makes -- the library
+then compares the grid with the copy its tables were built from (VP_FLAG_VERIFY_ACCEL).
+
+    python tools/bench_dropin.py [--shape R2|R1|both] [--occ same|fresh|both] [--front compiled|python|both]
+                                 [--views 16] [--reps 3] [--phases]
+
+Per line: ms per call, Mvoxel-views/s, GB/s of ALGORITHMIC bytes of the call (hit pixels' rows + output-row read-modify-write
++ ID image write and read + counts: SURVEY 8d) and that as a fraction of the 8 TB/s HBM peak.  --phases adds the library's
+own HIP-event times per kernel group (an extra pass; the events cost a few microseconds per call, so they stay out of the
+timed loop)."""
+import argparse
 import os
 import sys
 import time
@@ -11,31 +20,75 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import project_features_cuda as m  # noqa: E402  (the compiled extension)
 import project_features_front as front  # noqa: E402
+import voxproj_host  # noqa: E402
 from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 
-dev = torch.device("cuda", 0)
-n_vox, W, H, C, NV = 200000, 968, 548, 512, 16
-s = make_scene(n_vox, 300, W, H, seed=0)
-feats = make_features_torch(NV, H, W, C, dev, seed=0)
-occ32 = torch.from_numpy(s.occ).to(dev)
-occ = occ32.unsqueeze(0).long().contiguous()
-c2w = torch.from_numpy(s.c2w).to(dev)
-intr = torch.from_numpy(s.intr[None]).to(dev)
-opts = torch.from_numpy(s.opts())
-origin = torch.from_numpy(s.grid_origin)
-count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
-out = torch.zeros(n_vox + 1, C, device=dev)
-pm = torch.tensor([False])
-for fresh in (False, True):
-    for fn, name in ((m.project_features_cuda, "compiled"), (front.project_features_cuda_py, "python")):
-        ts = []
-        for rep in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for v in range(NV):
-                o = occ32.unsqueeze(0).long().contiguous() if fresh else occ
-                fn(feats[v:v + 1].unsqueeze(0), o, c2w[v].reshape(-1).contiguous(), intr, opts, count, out, pm, origin, s.voxel_size)
-            ts.append((time.perf_counter() - t0) / NV)
-        t = min(ts)
-        print(f"{'fresh occupancy tensor per call' if fresh else 'same occupancy tensor':32s} {name:9s} {t * 1e3:.3f} ms/call  "
-              f"{n_vox / t / 1e6:.0f} Mvoxel-views/s  ({W * H * C * 4 / t / 1e9:.0f} GB/s of feature rows)")
+SHAPES = {"R2": (200000, 968, 548, 512), "R1": (80000, 484, 274, 512)}
+
+
+def run(shape, occ_modes, fronts, NV, reps, phases):
+    dev = torch.device("cuda", 0)
+    n_vox, W, H, C = SHAPES[shape]
+    s = make_scene(n_vox, 300 if shape == "R2" else 100, W, H, seed=0)
+    feats = make_features_torch(NV, H, W, C, dev, seed=0)
+    occ32 = torch.from_numpy(s.occ).to(dev)
+    occ = occ32.unsqueeze(0).long().contiguous()
+    c2w = torch.from_numpy(s.c2w).to(dev)
+    vm = [c2w[v].reshape(-1).contiguous() for v in range(NV)]
+    intr = torch.from_numpy(s.intr[None]).to(dev)
+    opts = torch.from_numpy(s.opts())
+    origin = torch.from_numpy(s.grid_origin)
+    count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
+    out = torch.zeros(n_vox + 1, C, device=dev)
+    pm = torch.tensor([False])
+    # algorithmic bytes of the NV calls (deterministic): one untimed pass
+    algo = 0
+    for v in range(NV):
+        count.zero_()
+        m.project_features_cuda(feats[v:v + 1].unsqueeze(0), occ, vm[v], intr, opts, count, out, pm, origin, s.voxel_size)
+        ph, nt = int(count.sum().item()), int((count > 0).sum().item())
+        algo += ph * C * 4 + nt * C * 4 * 2 + H * W * 4 * 2 + (n_vox + 1) * 4 * 2
+    algo /= NV
+    for fresh in occ_modes:
+        for name in fronts:
+            fn = m.project_features_cuda if name == "compiled" else front.project_features_cuda_py
+            ts = []
+            for rep in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for v in range(NV):
+                    o = occ32.unsqueeze(0).long().contiguous() if fresh else occ
+                    fn(feats[v:v + 1].unsqueeze(0), o, vm[v], intr, opts, count, out, pm, origin, s.voxel_size)
+                ts.append((time.perf_counter() - t0) / NV)
+            t = min(ts)
+            line = (f"{shape} {'fresh occupancy tensor per call' if fresh else 'same occupancy tensor':32s} {name:9s} {t * 1e3:.4f} ms/call  "
+                    f"{n_vox / t / 1e6:.0f} Mvoxel-views/s  {algo / t / 1e9:.0f} GB/s algorithmic = {algo / t / 8e12:.3f} of peak "
+                    f"({W * H * C * 4 / t / 1e9:.0f} GB/s of feature-map bytes)")
+            if phases:
+                voxproj_host.profile_enable(True)
+                for v in range(NV):
+                    o = occ32.unsqueeze(0).long().contiguous() if fresh else occ
+                    fn(feats[v:v + 1].unsqueeze(0), o, vm[v], intr, opts, count, out, pm, origin, s.voxel_size)
+                p = voxproj_host.profile_read()
+                voxproj_host.profile_enable(False)
+                line += (f"  | per call, HIP events: prep {p['prep_ms'] / NV * 1e3:.1f} us, march+worklist {p['first_hit_ms'] / NV * 1e3:.1f} us, "
+                         f"gather {p['gather_ms'] / NV * 1e3:.1f} us, heavy launch {p['heavy_ms'] / NV * 1e3:.1f} us")
+            print(line, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="both", choices=("R2", "R1", "both"))
+    ap.add_argument("--occ", default="both", choices=("same", "fresh", "both"))
+    ap.add_argument("--front", default="both", choices=("compiled", "python", "both"))
+    ap.add_argument("--views", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--phases", action="store_true")
+    a = ap.parse_args()
+    for shape in (("R2", "R1") if a.shape == "both" else (a.shape,)):
+        run(shape, {"same": (False,), "fresh": (True,), "both": (False, True)}[a.occ],
+            ("compiled", "python") if a.front == "both" else (a.front,), a.views, a.reps, a.phases)
+
+
+if __name__ == "__main__":
+    main()
