@@ -75,6 +75,15 @@
         else hipLaunchKernelGGL((k_gather<4, 1, 4, MERGED, 1>), __VA_ARGS__);               \
     } while (0)
 
+// the one-view gather (vp_gather.h, k_gather_one)
+#define VP_DISPATCH_GATHER_ONE(VEC_OK, C, ...)                                    \
+    do {                                                                          \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather_one<1, 8, VP_F16_U>), __VA_ARGS__);    \
+        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather_one<2, 4, 4>), __VA_ARGS__); \
+        else if (VEC_OK) hipLaunchKernelGGL((k_gather_one<1, 4, 4>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((k_gather_one<4, 1, 4>), __VA_ARGS__);                  \
+    } while (0)
+
 // rows in flight per wavefront in the fp16 gather
 #ifndef VP_F16_U
 #define VP_F16_U 4
@@ -273,11 +282,17 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
 #endif
     const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
+    // One-view calls (the drop-in module's, the parity aggregator's) take the one-view gather: a fixed grid of wavefronts
+    // dealt the size-ordered list, a wavefront's boxes computed one voxel per lane, the next voxel's tile and row fetched
+    // under the current voxel's rows (vp_gather.h, k_gather_one).  VP_OPT_ONE_VIEW_GATHER = 0 keeps k_gather as the A/B arm.
+    const bool one_view = (long long)B * V == 1 && rec.opt_one_view != 0;
+#define VP_LAUNCH_WORKLIST(STREAM)                                                                                              \
+    hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, STREAM, (const int *)cnt_call,   \
+                       heavy_t, (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi)
     if (gather_only) {
         // the work list of the new row range, from the histogram the previous call's march left
         VP_HIP(hipMemsetAsync(status + ST_WORK0, 0, WORK_CLASSES * sizeof(int), s0));
-        hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, s0, (const int *)cnt_call, heavy_t,
-                           (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi);
+        VP_LAUNCH_WORKLIST(s0);
     }
     if (!gather_only) {
         ProfSpan sp; sp.begin(0, s1);
@@ -319,8 +334,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // the gather's work list: touched voxels by size class, largest first (needs the finished histogram); its trailing
         // workgroups compute the view table, which is phase 2's too -- behind the march, not in front of it (in pipelined
         // mode a kernel with that many registers waits for a wavefront of the previous call's gather to retire)
-        hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, s1, (const int *)cnt_call, heavy_t,
-                           (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi);
+        VP_LAUNCH_WORKLIST(s1);
         sp.end();
     }
     if (pipe && !gather_only) VP_HIP(hipEventRecord(ps->fh_done[q], s1));
@@ -340,13 +354,26 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const bool small_image = merged_heavy && (long long)H * W <= GATHER_G32_SMALL_IMAGE;   // grouping needs views to group
     g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
     if (pipe && !gather_only) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
+    if (one_view) {
+        // a fixed number of workgroups per CU: 4 (what the 2-KiB-row instantiation's 107 VGPRs admit) in a blocking call, 3
+        // beside the next call's march in job mode -- wavefronts that stay for the whole launch must leave the march room.
+        // VP_OPT_ONE_VIEW_GATHER = n > 0 overrides it.
+        ProfSpan sp; sp.begin(2, s0);
+        const int per_cu = rec.opt_one_view > 0 ? (int)std::min<long long>(rec.opt_one_view, 256) : pipe ? 3 : 4;
+        const long long want = (long long)device_cus() * per_cu;
+        const long long cap = (n_rows - 1 + 3) / 4;           // never more wavefronts than voxel IDs
+        const unsigned nblk = (unsigned)std::max<long long>(1, std::min(want, cap));
+        g.heavy_blocks = heavy_t != 2147483647 ? (int)std::min<unsigned>(HEAVY_BLOCKS, nblk) : 0;
+        if (n_rows > 1) VP_DISPATCH_GATHER_ONE(vec_ok, C, dim3(nblk), dim3(256), 0, s0, g, p);
+        sp.end();
+    }
     // (with VP_FLAG_SERIAL_SUMS no voxel can be heavy: the launch -- 5 us of a 0.1-ms one-view call -- is left out)
-    if (!merged_heavy && heavy_t != 2147483647) {
+    if (!one_view && !merged_heavy && heavy_t != 2147483647) {
         ProfSpan sp; sp.begin(3, s0);
         VP_DISPATCH_KVU(k_gather_heavy, vec_ok, C, dim3(HEAVY_BLOCKS), dim3(GW_ALONE * 64), 0, s0, g, p);
         sp.end();
     }
-    {
+    if (!one_view) {
         ProfSpan sp; sp.begin(2, s0);
         const dim3 ggrid(g.heavy_blocks + (blocks_n > 0 ? blocks_n : 0));
         if (ggrid.x == 0) { /* n_rows == 1: only the dummy row 0, nothing to gather */ }
@@ -706,6 +733,7 @@ int vp_workspace_set_option(void *workspace, int option, long long value)
         rec->opt_march_lds_kb = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ROW_BEGIN:       rec->opt_row_begin = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ROW_END:         rec->opt_row_end = value >= 0 ? value : -1; return VP_OK;
+    case VP_OPT_ONE_VIEW_GATHER: rec->opt_one_view = value >= 0 ? value : -1; return VP_OK;
     default: return fail(VP_EINVAL, "unknown workspace option %d", option);
     }
 }

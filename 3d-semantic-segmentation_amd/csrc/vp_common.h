@@ -100,6 +100,7 @@ struct WsState {
     long long opt_heavy_t = -1;
     long long opt_march_lds_kb = -1;
     long long opt_row_begin = -1, opt_row_end = -1;     // VP_OPT_ROW_BEGIN / _END: phase 2 gathers IDs in [begin, end)
+    long long opt_one_view = -1;                        // VP_OPT_ONE_VIEW_GATHER: 0 = one-view calls through k_gather (A/B arm)
     // arguments of the last vp_project_features call (VP_FLAG_GATHER_ONLY repeats its phase 2 on another row range)
     int last_B = 0, last_V = 0, last_H = 0, last_W = 0, last_C = 0, last_q = 0;
     bool last_f16 = false, last_ranged = false;
@@ -153,6 +154,22 @@ void ws_forget(const void *workspace)
     }
     pipe_destroy(st->pipe);
     delete st;
+}
+
+// compute units of the calling thread's current device (cached per device ordinal)
+int device_cus()
+{
+    static std::mutex mu;
+    static std::unordered_map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+    return n;
 }
 
 bool pipe_open(PipeState &ps)

@@ -686,4 +686,113 @@ __global__ __launch_bounds__(GW_ALONE * 64) void k_gather_heavy(GatherArgs g, Pa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-view calls (B*V == 1): what the unchanged reference pipeline issues, once per image (debug_project_features.py:201-208),
+// and what the aggregator's parity mode issues.  A one-view gather is SHORT -- R2: ~27 k touched voxels of ~20 pixels each,
+// 1.09 GB, a quarter of a millisecond -- so what k_gather spends per voxel outside the row loads is most of it: a workgroup
+// launched per 4 voxel IDs of the scene (50 000 for R2, 45 % of which find nothing to do), and in every wavefront a chain
+// of dependent steps before the first row load goes out (work-list entry -> cell of the voxel -> view entry -> box on one
+// lane -> ID tile -> ballot).  Here:
+//   * the grid is a fixed number of wavefronts (a few per SIMD); wavefront w takes the entries w, w + NW, w + 2 NW, ... of
+//     the size-ordered work list -- a static deal of a list that is sorted longest-first, no queue word to contend for;
+//   * lane j of the wavefront takes the j-th of ITS entries: the IDs, cells and pixel counts of all the wavefront's voxels
+//     arrive in one round of loads instead of one chain per voxel, and their pixel boxes are computed side by side, one
+//     voxel per lane (in k_gather the box computation is laid out lane = view: for one view, ~350 VALU instructions on ONE
+//     lane at the head of every voxel's chain);
+//   * while voxel j's rows stream, the ID tile and the output row of voxel j + 1 are already in flight.
+// Every voxel is still summed by one wavefront in (y, x) order from the row already in `out`: the oracle's bits.  Voxels
+// above the heavy threshold go to the first workgroups of the same launch (four wavefronts per voxel, as in k_gather),
+// which join the deal afterwards.
+// ------------------------------------------------------------------------------------------------
+template <int K, int VEC, int U>
+__global__ __launch_bounds__(256) void k_gather_one(GatherArgs g, Params p)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ __attribute__((aligned(16))) float part[GW_MERGED][64 * K * VEC];
+    __shared__ int part_found[GW_MERGED];
+    if ((int)blockIdx.x < g.heavy_blocks) {
+        const int n_heavy = *g.n_heavy;
+        for (int h = blockIdx.x; h < n_heavy; h += g.heavy_blocks) {
+            const int id = g.heavy_list[h];
+            if (id < g.row_lo || id >= g.row_hi) continue;
+            const int expected = g.cnt_call[id];
+            if (!gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, false)) {
+                if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+                gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, true);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const long long NW = (long long)gridDim.x * 4;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int n[WORK_CLASSES];
+    long long total = 0;
+#pragma unroll
+    for (int k = 0; k < WORK_CLASSES; k++) { n[k] = g.work_n[k]; total += n[k]; }
+    const int W = p.width, H = p.height, C = p.C;
+    constexpr int CB = 64 * K * VEC;
+    const float *fv = g.feats;
+    const int *hv = g.hit;
+    for (long long base = w; base < total; base += 64 * NW) {
+        // lane j: the j-th entry of this wavefront in this batch -- ID, box, pixel count
+        long long r = base + (long long)lane * NW;
+        int id_l = 0;
+        if (r < total) {
+#pragma unroll
+            for (int k = WORK_CLASSES - 1; k >= 0; k--) {
+                if (id_l == 0 && r < n[k]) id_l = g.work[(long long)k * p.n_rows + r];
+                r -= n[k];
+            }
+        }
+        int bx0_l = 0, by0_l = 0, bx1_l = -1, by1_l = -1, cnt_l = 0;      // x1 < x0: no box, scan the whole image
+        if (id_l != 0) {
+            cnt_l = g.cnt_call[id_l];
+            float cxw, cyw, czw;
+            if (voxel_centre(g, p, 0, id_l, cxw, cyw, czw)) {
+                int a0, a1, a2, a3;
+                if (voxel_box(g.viewtab[0], g.intr[0], g.intr[1], g.intr[2], g.intr[3], cxw, cyw, czw, box_half_edge(p), near_plane(p),
+                              W, H, a0, a1, a2, a3)) { bx0_l = a0; by0_l = a1; bx1_l = a2; by1_l = a3; }
+            }
+        }
+        const int nv = __popcll(__ballot(id_l != 0));      // the entries of a wavefront fill its lanes from 0 upwards
+        // the first voxel's ID tile and output row
+        int id = 0, x0 = 0, y0 = 0, x1 = -1, y1 = -1, expected = 0, tile = 0;
+        Acc<K, VEC> acc;
+        auto fetch = [&](int j) {
+            id = __builtin_amdgcn_readlane(id_l, j);
+            expected = __builtin_amdgcn_readlane(cnt_l, j);
+            x0 = __builtin_amdgcn_readlane(bx0_l, j); y0 = __builtin_amdgcn_readlane(by0_l, j);
+            x1 = __builtin_amdgcn_readlane(bx1_l, j); y1 = __builtin_amdgcn_readlane(by1_l, j);
+            if (x1 < x0 || y1 < y0) { x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1; }      // no box: the whole image
+            tile = first_tile_id(hv, W, x0, y0, x1, y1, lane);
+            acc_load<K, VEC>(acc, g.out + (long long)id * C, 0, C, lane);
+        };
+        if (nv > 0) fetch(0);
+        for (int j = 0; j < nv; j++) {
+            const int cid = id, cx0 = x0, cy0 = y0, cx1 = x1, cy1 = y1, cexp = expected, ctile = tile;
+            Acc<K, VEC> cacc = acc;
+            if (j + 1 < nv) fetch(j + 1);       // in flight while this voxel's rows stream
+            for (int cb = 0; cb < C; cb += CB) {
+                float *orow = g.out + (long long)cid * C + cb;
+                if (cb > 0) acc_load<K, VEC>(cacc, orow, cb, C, lane);
+                int found = 0;
+                scan_box<K, VEC, U>(fv, hv, W, C, cid, cx0, cy0, cx1, cy1, cb, lane, cacc, found, cb == 0, ctile);
+                if (found != cexp) {
+                    // the box missed pixels (an ID labelling several cells, a degenerate pose ...): redo over the whole
+                    // image from the row as it still is in memory.  Correctness never depends on the boxes.
+                    if (lane == 0 && cb == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+                    acc_load<K, VEC>(cacc, orow, cb, C, lane);
+                    found = 0;
+                    scan_box<K, VEC, U>(fv, hv, W, C, cid, 0, 0, W - 1, H - 1, cb, lane, cacc, found);
+                }
+                acc_store<K, VEC, false>(cacc, orow, cb, C, lane);
+                if (cb == 0 && lane == 0) {
+                    g.count[cid] += found;
+                    if (g.views_hit) g.views_hit[cid] += found > 0;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace

@@ -176,7 +176,13 @@ __global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int
             const bool mine = (unsigned)hdr[ST_HDR_MAGIC] == magic && (unsigned)hdr[ST_HDR_GEN] == gen;
             if (!mine || (unsigned)hdr[ST_HDR_TABLES] != tables) {
                 v = 1;
-                if (!mine) { sticky[ST_STICKY_BADID] = 0; sticky[ST_STICKY_STUCK] = 0; }   // not this record's words: garbage
+                if (!mine) {
+                    // not this record's words: garbage.  The block becomes this record's from here on -- with "no tables" in
+                    // the header, so every later call that trusts tables is stale too -- and vp_workspace_status, which
+                    // believes sticky words only under its own record's header, reports the condition
+                    sticky[ST_STICKY_BADID] = 0; sticky[ST_STICKY_STUCK] = 0;
+                    sticky[ST_HDR_MAGIC] = (int)magic; sticky[ST_HDR_GEN] = (int)gen; sticky[ST_HDR_TABLES] = 0;
+                }
                 sticky[ST_STICKY_STALE] = 1;
             }
         }

@@ -57,6 +57,7 @@ VP_OPT_HEAVY_THRESHOLD = 1
 VP_OPT_MARCH_LDS_KB = 2
 VP_OPT_ROW_BEGIN = 3
 VP_OPT_ROW_END = 4
+VP_OPT_ONE_VIEW_GATHER = 5
 
 
 class VoxprojError(RuntimeError):
@@ -208,7 +209,7 @@ class Workspace:
         state = (_options_version, tuple(sorted(self.options.items())))
         if self.buf is None or self._applied == state:
             return
-        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1, VP_OPT_ROW_BEGIN: -1, VP_OPT_ROW_END: -1}
+        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1, VP_OPT_ROW_BEGIN: -1, VP_OPT_ROW_END: -1, VP_OPT_ONE_VIEW_GATHER: -1}
         merged.update(_default_options)
         merged.update(self.options)
         for opt, val in merged.items():
@@ -263,7 +264,7 @@ def get_workspace(device):
 
 def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3, voxel_size,
                          workspace=None, sync=True, reuse_accel=None, exact_march=None, pipeline=False,
-                         views_hit=None, verify_accel=False, gather_only=False, serial_sums=False):
+                         views_hit=None, verify_accel=False, gather_only=False, serial_sums=False, extra_flags=0):
     """Call vp_project_features (or vp_project_features_f16 when ``feats`` is float16) on torch CUDA tensors
     (already validated by the caller).
 
@@ -299,7 +300,7 @@ def project_features_raw(feats, occ, vmi, intr, opts5, count, out, grid_origin3,
     flags = ((VP_FLAG_SYNC if (sync and not pipeline) else 0) | (VP_FLAG_REUSE_ACCEL if reuse_accel else 0)
              | (VP_FLAG_EXACT_MARCH if exact_march else 0) | (VP_FLAG_PIPELINE if pipeline else 0)
              | (VP_FLAG_VERIFY_ACCEL if (verify_accel and sync and not pipeline and not reuse_accel and ACCEL_CACHE) else 0)
-             | (VP_FLAG_GATHER_ONLY if gather_only else 0) | (VP_FLAG_SERIAL_SUMS if serial_sums else 0))
+             | (VP_FLAG_GATHER_ONLY if gather_only else 0) | (VP_FLAG_SERIAL_SUMS if serial_sums else 0) | int(extra_flags))
     o = (ctypes.c_float * 5)(*[float(v) for v in opts5])
     g = (ctypes.c_float * 3)(*[float(v) for v in grid_origin3])
     stream = torch.cuda.current_stream(feats.device).cuda_stream

@@ -571,7 +571,7 @@ def test_ray_parameter_closed_form_over_many_increments(oracle_mod):
             _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, opts, np.array([-2.1, -1.7, 0.05], np.float32), 0.2, 151)
 
 
-@pytest.mark.parametrize("lds_kb", [None, 0, 80])
+@pytest.mark.parametrize("lds_kb", [None, 0, 64])
 def test_pipelined_occupancy_knob_stays_exact(oracle_mod, lds_kb):
     # the march's occupancy cap in pipelined mode (a dynamic-LDS reservation, VP_OPT_MARCH_LDS_KB) is a scheduling hint only
     import voxproj_host
@@ -601,6 +601,13 @@ def test_pipelined_occupancy_knob_stays_exact(oracle_mod, lds_kb):
     voxproj_host.workspace_status(ws, dev)
     assert np.array_equal(count_t.cpu().numpy(), count)
     assert out_t.cpu().numpy().tobytes() == out.tobytes()
+    # a reservation beyond a kernel's 64-KiB dynamic-LDS limit is refused when it is SET (it used to fail every
+    # launch on the workspace with a generic HIP error, in pipelined mode calls later); the workspace stays usable
+    with pytest.raises(voxproj_host.VoxprojError, match="limited to 64 KiB"):
+        voxproj_host.check(voxproj_host.lib().vp_workspace_set_option(ws.ptr(), voxproj_host.VP_OPT_MARCH_LDS_KB, 80))
+    voxproj_host.project_features_raw(feats_t[:, :5], occ_t, vmis[0], intr_t, [float(v) for v in s.opts()], count_t, out_t,
+                                      [float(v) for v in s.grid_origin], s.voxel_size, workspace=ws, sync=True)
+    ws.release()
 
 
 def test_fp16_feature_maps_give_the_fp32_bits(oracle_mod):

@@ -84,7 +84,12 @@ def main():
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--phases", action="store_true")
+    ap.add_argument("--one-view", type=int, default=-1, help="VP_OPT_ONE_VIEW_GATHER of both fronts' workspaces: 0 = the general "
+                    "gather kernel (A/B arm), n > 0 = the one-view kernel with n workgroups per CU, -1 = the library's default")
     a = ap.parse_args()
+    if a.one_view >= 0:
+        m.set_workspace_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view)
+        voxproj_host.set_default_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view)
     for shape in (("R2", "R1") if a.shape == "both" else (a.shape,)):
         run(shape, {"same": (False,), "fresh": (True,), "both": (False, True)}[a.occ],
             ("compiled", "python") if a.front == "both" else (a.front,), a.views, a.reps, a.phases)
