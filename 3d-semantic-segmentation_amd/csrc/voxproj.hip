@@ -182,7 +182,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     int *status = (int *)(ws + l.status[q]);
     int *cell_of_id = (int *)(ws + l.cell_of_id);
     unsigned long long *mask64 = (unsigned long long *)(ws + l.mask64);
-    ulonglong2 *near2 = (ulonglong2 *)(ws + l.near2);
+    NearRec *near2 = (NearRec *)(ws + l.near2);
     unsigned char *dist = (unsigned char *)(ws + l.dist);
     unsigned char *dist_tmp = (unsigned char *)(ws + l.dist_tmp);
     int *cnt_call = (int *)(ws + l.cnt_call[q]);
@@ -355,11 +355,13 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
     if (pipe && !gather_only) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
     if (one_view) {
-        // a fixed number of workgroups per CU: 4 (what the 2-KiB-row instantiation's 107 VGPRs admit) in a blocking call, 3
-        // beside the next call's march in job mode -- wavefronts that stay for the whole launch must leave the march room.
+        // a fixed number of workgroups per CU.  The kernel's registers admit 4 at a time; 16 are launched, so that the
+        // dispatcher evens out what the static deal leaves uneven (one R2 view: 2 / 4 / 8 / 16 / 32 / 64 per CU -> 229 / 219 /
+        // 210-226 / 217 / 220 / 222 us, R1: 99 / 95 / 87 / 83 / 83.5 / 82.6 us, profiles/r04_one_view_gather.log) -- a
+        // quarter of the workgroups k_gather launches for the same call, none of them without work.
         // VP_OPT_ONE_VIEW_GATHER = n > 0 overrides it.
         ProfSpan sp; sp.begin(2, s0);
-        const int per_cu = rec.opt_one_view > 0 ? (int)std::min<long long>(rec.opt_one_view, 256) : pipe ? 3 : 4;
+        const int per_cu = rec.opt_one_view > 0 ? (int)std::min<long long>(rec.opt_one_view, 256) : 16;
         const long long want = (long long)device_cus() * per_cu;
         const long long cap = (n_rows - 1 + 3) / 4;           // never more wavefronts than voxel IDs
         const unsigned nblk = (unsigned)std::max<long long>(1, std::min(want, cap));

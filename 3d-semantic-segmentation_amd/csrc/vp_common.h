@@ -230,6 +230,17 @@ inline unsigned tables_key(int B, int dimz, int dimy, int dimx, long long n_rows
     return k ? k : 1u;     // 0 means "no tables"
 }
 
+// Near field of one 4x4x4 block (blocks within one block of geometry): for each of its 64 cells the Chebyshev distance in
+// CELLS to the nearest occupied cell, capped at 7 ("7 or more"), as three bit planes (bit = z%4*16 + y%4*4 + x%4;
+// nd = p0 | p1 << 1 | p2 << 2; nd == 0 <=> the cell is occupied), and a copy of the block's entry of the block distance
+// field, so that the march fetches everything it needs about a block with ONE 32-byte read.  Round 3 kept two planes
+// (distances up to 3): 8.4 of the 13.1 samples a ray evaluated lay within two blocks of the surface, where a bound of 2 or 3
+// allows skips of one and three samples only.
+struct __attribute__((aligned(32))) NearRec {
+    unsigned long long p0, p1, p2;
+    unsigned long long dist;      // the block's Chebyshev distance in blocks to the nearest non-empty block (0 .. 255)
+};
+
 // per (b,v) entry of the view table: world->camera affine map (inverse of the c2w 3x3) + flags
 struct ViewEntry {
     float inv[9];   // row-major inverse of the upper-left 3x3 of c2w
@@ -267,7 +278,7 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
     l.status[1] = off;   off += align256(ST_WORDS * sizeof(int));
     l.cell_of_id = off;  off += align256(size_t(B) * size_t(n_rows) * sizeof(int));
     l.mask64 = off;      off += align256(size_t(B) * l.nblk * sizeof(unsigned long long));
-    l.near2 = off;       off += align256(size_t(B) * l.nblk * 16);
+    l.near2 = off;       off += align256(size_t(B) * l.nblk * sizeof(NearRec));
     l.dist = off;        off += align256(size_t(B) * l.nblk);
     l.dist_tmp = off;    off += align256(size_t(B) * l.nblk);
     l.occ_copy = off;    off += align256(size_t(B) * size_t(dimz) * dimy * dimx * sizeof(int));

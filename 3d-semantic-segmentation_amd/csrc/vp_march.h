@@ -17,7 +17,7 @@ namespace {
 //   * the cell index roundf((p - origin)/vs) is taken from the product with 1/vs when that product is
 //     farther than 2^-21*|q| from a rounding boundary (then both roundings agree), and from the IEEE
 //     division otherwise;
-//   * near geometry the bound D is the cell's own Chebyshev distance (0..3, two 64-bit bit planes per 4x4x4 block,
+//   * near geometry the bound D is the cell's own Chebyshev distance (0..7, three 64-bit bit planes per 4x4x4 block,
 //     held in registers while the ray stays in the block); D = 0 means "this cell is occupied" and only then is
 //     the int64 grid read for the ID;
 //   * the (u,v) bounds test of K.cu:53-61 is evaluated, with the reference's exact operations, only
@@ -29,7 +29,7 @@ struct FirstHitArgs {
     const long long *occ;
     const float *vmi;
     const float *intr;
-    const ulonglong2 *near2;
+    const NearRec *near2;
     const unsigned char *dist;
     int nby, nbx;
     long long nblk;
@@ -48,7 +48,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     const long long *__restrict__ occ = fa.occ;
     const float *__restrict__ vmi = fa.vmi;
     const float *__restrict__ intr = fa.intr;
-    const ulonglong2 *__restrict__ near2 = fa.near2;
+    const NearRec *__restrict__ near2 = fa.near2;
     const unsigned char *__restrict__ dist = fa.dist;
     const int nby = fa.nby, nbx = fa.nbx;
     const long long nblk = fa.nblk;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
             t += p.inc;
         }
     } else {
-        const ulonglong2 *near_b = near2 + (long long)b * nblk;
+        const NearRec *near_b = near2 + (long long)b * nblk;
         const unsigned char *dist_b = dist + (long long)b * nblk;
         const float rvs = 1.0f / p.vs;
         // upper bound of the per-step motion in cells (1% covers the rounding of t += inc and of rvs)
@@ -127,14 +127,68 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
         const float thr = leap_ok ? 0.5f - span * 0x1p-21f : -1.0f;
         unsigned cur_blk = 0xffffffffu;
         int cur_d = 0;
-        unsigned long long cur_lo = 0ull, cur_hi = 0ull;
+        unsigned long long cur_p0 = 0ull, cur_p1 = 0ull, cur_p2 = 0ull;
 #ifdef VP_DIAG
-        int dbg_leap = 0, dbg_fine = 0, dbg_far = 0;
+        int dbg_leap = 0, dbg_fine = 0;
 #endif
         // binade cache of the closed-form t advance (derivation: "Closed-form advance" in vp_tables.h): valid while t < bT2
         float bT2 = 0.0f, bTu = 0.0f, bg = 0.0f, brg = 0.0f;
-        // S repetitions of t = fl(t + inc), reproduced exactly (stops early once t >= tEnd: the reference's loop is over then)
-        auto advance = [&](int S) {
+        while (t < tEnd) {
+            const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
+            const float ax = px - p.ox, ay = py - p.oy, az = pz - p.oz;
+            const float qx = ax * rvs, qy = ay * rvs, qz = az * rvs;
+            const float rx = rintf(qx), ry = rintf(qy), rz = rintf(qz);
+            const bool safe = (fabsf(qx - rx) < thr) & (fabsf(qy - ry) < thr) & (fabsf(qz - rz) < thr);
+            int ix = (int)rx, iy = (int)ry, iz = (int)rz;   // exact when safe (|q| < 2^17)
+            if (__builtin_expect(!safe, 0)) {
+                ix = f2i_sat(round_half_away(ax / p.vs));
+                iy = f2i_sat(round_half_away(ay / p.vs));
+                iz = f2i_sat(round_half_away(az / p.vs));
+            }
+            int D = 0;   // lower bound on the Chebyshev cell distance from (ix,iy,iz) to an occupied cell
+            const bool ing = ((unsigned)ix < (unsigned)p.dimx) & ((unsigned)iy < (unsigned)p.dimy) & ((unsigned)iz < (unsigned)p.dimz);
+            if (__builtin_expect(ing, 1)) {
+                const unsigned blk = ((unsigned)(iz >> 2) * (unsigned)nby + (unsigned)(iy >> 2)) * (unsigned)nbx + (unsigned)(ix >> 2);
+                if (blk != cur_blk) {
+                    cur_blk = blk;
+                    // one 32-byte record: the block's distance in blocks and the three bit planes of its cells' distances
+                    // (the planes are only meaningful when cur_d <= 1)
+                    const NearRec n3 = near_b[blk];
+                    cur_d = (int)n3.dist;
+                    cur_p0 = n3.p0; cur_p1 = n3.p1; cur_p2 = n3.p2;
+                }
+                const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
+                const int nd = (int)((cur_p0 >> bit) & 1ull) | ((int)((cur_p1 >> bit) & 1ull) << 1) | ((int)((cur_p2 >> bit) & 1ull) << 2);
+                D = cur_d <= 1 ? nd : (cur_d - 1) * 4 + 1;
+                if (__builtin_expect((cur_d <= 1) & (nd == 0), 0)) {
+                    const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
+                    const float u = fx * (camx / camz) + mx;
+                    const float v = fy * (camy / camz) + my;
+                    if ((u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh)) {
+                        id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
+                        if (id != 0) break;
+                    }
+                }
+            } else if (leap_ok) {
+                const int lim = 1 << 29;
+                const int jx = min(max(ix, -lim), lim), jy = min(max(iy, -lim), lim), jz = min(max(iz, -lim), lim);
+                const int ex = jx < 0 ? -jx : (jx >= p.dimx ? jx - p.dimx + 1 : 0);
+                const int ey = jy < 0 ? -jy : (jy >= p.dimy ? jy - p.dimy + 1 : 0);
+                const int ez = jz < 0 ? -jz : (jz >= p.dimz ? jz - p.dimz + 1 : 0);
+                const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
+                const int kx = min(max(jx, 0), p.dimx - 1), ky = min(max(jy, 0), p.dimy - 1), kz = min(max(jz, 0), p.dimz - 1);
+                const int cb_ = ((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2);
+                const int dd = dist_b[cb_];
+                const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
+                D = max(dbox, din - dbox);
+            }
+#ifdef VP_DIAG
+            if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
+#endif
+            // advance by 1 + J samples, J = floor((D - 1.5) / dcell) of them provably unable to reach an occupied
+            // cell; the running sum t is reproduced exactly by the closed form, with the binade constants cached
+            // across evaluations
+            int S = 1 + (D >= 2 ? (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f) : 0);
             for (;;) {
                 if (t >= bT2) {
                     const unsigned eb = __float_as_uint(t) & 0x7f800000u;
@@ -155,134 +209,10 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
                 S -= 1;
                 if (S <= 0 || !(t < tEnd)) break;
             }
-        };
-        // FAR MODE (round 4).  A sample that cannot register a hit is only ever examined to decide how many samples can be
-        // skipped, and that decision needs a BOUND, not the reference's bits.  So while the bound allows a skip the ray's exact
-        // parameter is not advanced at all: `t` stays the exact running sum at the last sample that was evaluated exactly
-        // (the anchor) and `jp` counts the samples skipped since.  The sample that is jp additions past the anchor has the
-        // true parameter t_jp in t + jp*inc*[0.99, 1.01] (every addition adds inc to within 0.5 ulp(t) <= 0.01 inc: the
-        // tEnd < 1e5*inc guard), so the position computed from tt = t + jp*inc is within e = 0.01*jp*dcell cells of the true
-        // sample.  With c~ the cell of that approximate position and D a lower bound on the Chebyshev distance from c~ to any
-        // occupied cell, the true samples jp .. jp + J land in cells within 1 + e + J*dcell + 0.25 (fp slack, span guard) of
-        // c~: all empty when 1.5 + e + J*dcell <= D.  None of them can register a hit, so none needs the exact arithmetic
-        // (~50 VALU instructions per examined sample instead of ~100: no division-exact cell index, no closed-form advance).
-        // When the bound allows no skip (D - 1.5 - e < 0: an occupied cell may be next to the sample, or e has grown), or the
-        // end of the ray is within the error bar, the anchor is moved: t is advanced by exactly jp additions (closed form,
-        // bit-exact) and the march continues with the exact evaluation at that very sample; an exact evaluation that
-        // allows a skip hands back to far mode.  The two modes are two inner loops, so that the lanes of a wavefront (an
-        // 8x8 tile of neighbouring rays, which meet geometry at about the same sample) run each mode together instead of
-        // every iteration paying for both.
-        bool far = leap_ok;
-        int jp = 0;
-        while (t < tEnd) {
-            while (far) {
-                const float fj = (float)jp;
-                const float tt = t + fj * p.inc;
-                bool sync = !(tt + 0.011f * fj * p.inc < tEnd);      // the end of the ray within the error bar: decide exactly
-                int S = 0;
-                if (!sync) {
-                    const float qx = ((cpx + tt * wdx) - p.ox) * rvs, qy = ((cpy + tt * wdy) - p.oy) * rvs, qz = ((cpz + tt * wdz) - p.oz) * rvs;
-                    const int ix = (int)rintf(qx), iy = (int)rintf(qy), iz = (int)rintf(qz);      // |q| < 2^17
-                    int D;
-                    if (((unsigned)ix < (unsigned)p.dimx) & ((unsigned)iy < (unsigned)p.dimy) & ((unsigned)iz < (unsigned)p.dimz)) {
-                        const unsigned blk = ((unsigned)(iz >> 2) * (unsigned)nby + (unsigned)(iy >> 2)) * (unsigned)nbx + (unsigned)(ix >> 2);
-                        if (blk != cur_blk) {
-                            cur_blk = blk;
-                            const ulonglong2 n2 = near_b[blk];
-                            cur_d = dist_b[blk];
-                            cur_lo = n2.x; cur_hi = n2.y;
-                        }
-                        const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
-                        const int nd = (int)((cur_lo >> bit) & 1ull) | ((int)((cur_hi >> bit) & 1ull) << 1);
-                        D = cur_d <= 1 ? nd : (cur_d - 1) * 4 + 1;
-                    } else {
-                        const int ex = ix < 0 ? -ix : (ix >= p.dimx ? ix - p.dimx + 1 : 0);
-                        const int ey = iy < 0 ? -iy : (iy >= p.dimy ? iy - p.dimy + 1 : 0);
-                        const int ez = iz < 0 ? -iz : (iz >= p.dimz ? iz - p.dimz + 1 : 0);
-                        const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
-                        const int kx = min(max(ix, 0), p.dimx - 1), ky = min(max(iy, 0), p.dimy - 1), kz = min(max(iz, 0), p.dimz - 1);
-                        const int dd = dist_b[((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2)];
-                        const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
-                        D = max(dbox, din - dbox);
-                    }
-                    const float avail = (float)D - 1.5f - 0.01f * fj * dcell;
-                    sync = !(avail >= 0.0f);
-                    S = 1 + (int)fminf(avail * inv_dcell, 16777216.0f);
-#ifdef VP_DIAG
-                    dbg_far++;
-#endif
-                }
-                if (sync) far = false;
-                else jp += S;
-            }
-            // move the anchor to the sample far mode stopped at, and evaluate it exactly
-            if (jp > 0) { advance(jp); jp = 0; }
-            if (!(t < tEnd)) break;
-            do {
-                const float px = cpx + t * wdx, py = cpy + t * wdy, pz = cpz + t * wdz;
-                const float ax = px - p.ox, ay = py - p.oy, az = pz - p.oz;
-                const float qx = ax * rvs, qy = ay * rvs, qz = az * rvs;
-                const float rx = rintf(qx), ry = rintf(qy), rz = rintf(qz);
-                const bool safe = (fabsf(qx - rx) < thr) & (fabsf(qy - ry) < thr) & (fabsf(qz - rz) < thr);
-                int ix = (int)rx, iy = (int)ry, iz = (int)rz;   // exact when safe (|q| < 2^17)
-                if (__builtin_expect(!safe, 0)) {
-                    ix = f2i_sat(round_half_away(ax / p.vs));
-                    iy = f2i_sat(round_half_away(ay / p.vs));
-                    iz = f2i_sat(round_half_away(az / p.vs));
-                }
-                int D = 0;   // lower bound on the Chebyshev cell distance from (ix,iy,iz) to an occupied cell
-                const bool ing = ((unsigned)ix < (unsigned)p.dimx) & ((unsigned)iy < (unsigned)p.dimy) & ((unsigned)iz < (unsigned)p.dimz);
-                if (__builtin_expect(ing, 1)) {
-                    const unsigned blk = ((unsigned)(iz >> 2) * (unsigned)nby + (unsigned)(iy >> 2)) * (unsigned)nbx + (unsigned)(ix >> 2);
-                    if (blk != cur_blk) {
-                        cur_blk = blk;
-                        // both table reads go out together (the bit planes are only meaningful when cur_d <= 1)
-                        const ulonglong2 n2 = near_b[blk];
-                        cur_d = dist_b[blk];
-                        cur_lo = n2.x; cur_hi = n2.y;
-                    }
-                    const int bit = ((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3);
-                    const int nd = (int)((cur_lo >> bit) & 1ull) | ((int)((cur_hi >> bit) & 1ull) << 1);
-                    D = cur_d <= 1 ? nd : (cur_d - 1) * 4 + 1;
-                    if (__builtin_expect((cur_d <= 1) & (nd == 0), 0)) {
-                        const float camx = cdx * t, camy = cdy * t, camz = cdz * t;
-                        const float u = fx * (camx / camz) + mx;
-                        const float v = fy * (camy / camz) + my;
-                        if ((u >= 0.0f) && (u < fw) && (v >= 0.0f) && (v < fh)) {
-                            id = (int)occ_b[((long long)iz * p.dimy + iy) * p.dimx + ix];
-                            if (id != 0) break;
-                        }
-                    }
-                } else if (leap_ok) {
-                    const int lim = 1 << 29;
-                    const int jx = min(max(ix, -lim), lim), jy = min(max(iy, -lim), lim), jz = min(max(iz, -lim), lim);
-                    const int ex = jx < 0 ? -jx : (jx >= p.dimx ? jx - p.dimx + 1 : 0);
-                    const int ey = jy < 0 ? -jy : (jy >= p.dimy ? jy - p.dimy + 1 : 0);
-                    const int ez = jz < 0 ? -jz : (jz >= p.dimz ? jz - p.dimz + 1 : 0);
-                    const int dbox = max(ex, max(ey, ez));   // every occupied cell lies inside the grid box
-                    const int kx = min(max(jx, 0), p.dimx - 1), ky = min(max(jy, 0), p.dimy - 1), kz = min(max(jz, 0), p.dimz - 1);
-                    const int cb_ = ((kz >> 2) * nby + (ky >> 2)) * nbx + (kx >> 2);
-                    const int dd = dist_b[cb_];
-                    const int din = dd > 0 ? (dd - 1) * 4 + 1 : 0;
-                    D = max(dbox, din - dbox);
-                }
-#ifdef VP_DIAG
-                if (heavy_t < 0) { if (D >= 2) dbg_leap++; else dbg_fine++; }
-#endif
-                // this sample did not hit: the next one, or -- when D - 1.5 allows J = floor((D - 1.5) / dcell) more samples to be
-                // skipped, none of which can reach an occupied cell -- the one after those, counted from here in far mode
-                if (leap_ok & (D >= 2)) {
-                    jp = 1 + (int)fminf(((float)D - 1.5f) * inv_dcell, 16777216.0f);
-                    far = true;
-                } else {
-                    t += p.inc;
-                }
-            } while (!far && (t < tEnd));
-            if (id != 0) break;
         }
 #ifdef VP_DIAG
         if (heavy_t < 0) {   // diagnostic build only (make diag, VP_FLAG_DIAG_EVALS): per-ray evaluation counts instead of IDs
-            hit[((long long)bv * p.height + y) * p.width + x] = (min(dbg_far, 1023) << 20) | (min(dbg_leap, 1023) << 10) | min(dbg_fine, 1023);
+            hit[((long long)bv * p.height + y) * p.width + x] = (min(dbg_leap, 1023) << 10) | min(dbg_fine, 1023);
             return;
         }
 #endif

@@ -104,8 +104,11 @@ __global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__
 }
 
 // Near field: for every cell of every block within one block of an occupied block, the Chebyshev distance in
-// CELLS to the nearest occupied cell, capped at 3 ("3 or more"), stored as two bit planes per 4x4x4 block
-// (nd = bit of .x | bit of .y << 1; nd == 0 <=> the cell is occupied).  One wavefront per block.
+// CELLS to the nearest occupied cell, capped at NEAR_CAP ("7 or more"), stored as three bit planes per 4x4x4 block
+// (NearRec, vp_common.h; nd == 0 <=> the cell is occupied).  One wavefront per block, one lane per cell; the shells
+// of radius 1, 2, ... around the cell are searched until one holds an occupied cell.
+constexpr int NEAR_CAP = 7;
+
 __device__ __forceinline__ bool occ_bit(const unsigned long long *__restrict__ mask_b, int x, int y, int z,
                                         int dimz, int dimy, int dimx, int nby, int nbx)
 {
@@ -115,7 +118,7 @@ __device__ __forceinline__ bool occ_bit(const unsigned long long *__restrict__ m
 }
 
 __global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__restrict__ mask64,
-                                                    const unsigned char *__restrict__ dist, ulonglong2 *near2,
+                                                    const unsigned char *__restrict__ dist, NearRec *near2,
                                                     int dimz, int dimy, int dimx, int nbz, int nby, int nbx,
                                                     long long nblk, int B)
 {
@@ -126,24 +129,30 @@ __global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__
     const int b = (int)(wid / nreal);
     const int blk = (int)(wid - (long long)b * nreal);
     const unsigned long long *mask_b = mask64 + (long long)b * nblk;
-    int nd = 3;
-    if (dist[(long long)b * nblk + blk] <= 1) {
+    const int bd = dist[(long long)b * nblk + blk];
+    int nd = NEAR_CAP;
+    if (bd <= 1) {
         const int bz = blk / (nby * nbx), r = blk - bz * (nby * nbx), by = r / nbx, bx = r - by * nbx;
         const int x = bx * 4 + (lane & 3), y = by * 4 + ((lane >> 2) & 3), z = bz * 4 + (lane >> 4);
         if (occ_bit(mask_b, x, y, z, dimz, dimy, dimx, nby, nbx)) {
             nd = 0;
         } else {
-            for (int rad = 1; rad <= 2 && nd == 3; rad++)
-                for (int dz = -rad; dz <= rad && nd == 3; dz++)
-                    for (int dy = -rad; dy <= rad && nd == 3; dy++)
-                        for (int dx = -rad; dx <= rad; dx++) {
-                            if (max(abs(dx), max(abs(dy), abs(dz))) != rad) continue;
+            for (int rad = 1; rad < NEAR_CAP && nd == NEAR_CAP; rad++)
+                for (int dz = -rad; dz <= rad && nd == NEAR_CAP; dz++)
+                    for (int dy = -rad; dy <= rad && nd == NEAR_CAP; dy++) {
+                        // the shell of radius rad: whole rows on its z and y faces, the two end cells of a row elsewhere
+                        const int step = (abs(dz) == rad || abs(dy) == rad) ? 1 : 2 * rad;
+                        for (int dx = -rad; dx <= rad; dx += step)
                             if (occ_bit(mask_b, x + dx, y + dy, z + dz, dimz, dimy, dimx, nby, nbx)) { nd = rad; break; }
-                        }
+                    }
         }
     }
-    const unsigned long long lo = __ballot(nd & 1), hi = __ballot(nd & 2);
-    if (lane == 0) near2[(long long)b * nblk + blk] = make_ulonglong2(lo, hi);
+    const unsigned long long p0 = __ballot(nd & 1), p1 = __ballot(nd & 2), p2 = __ballot(nd & 4);
+    if (lane == 0) {
+        NearRec rec;
+        rec.p0 = p0; rec.p1 = p1; rec.p2 = p2; rec.dist = (unsigned long long)bd;
+        near2[(long long)b * nblk + blk] = rec;
+    }
 }
 
 // Workspace header (vp_common.h, WsState): initialise the status blocks of memory that does not carry this record's

@@ -114,6 +114,9 @@ def parse():
     ap.add_argument("--march-lds-kb", type=int, default=-1,
                     help="experiment: VP_OPT_MARCH_LDS_KB of the workspace (dynamic-LDS reservation of the march = its occupancy "
                          "cap beside a gather); -1 = the library's default (41 KiB = 3 workgroups per CU)")
+    ap.add_argument("--one-view-gather", type=int, default=-1,
+                    help="experiment: VP_OPT_ONE_VIEW_GATHER of every workspace (one-view calls: 0 = the general gather kernel, n > 0 = "
+                         "the one-view kernel with n workgroups per CU); -1 = the library's default")
     ap.add_argument("--no-split-collective", action="store_true",
                     help="multi-rank step: the TIMED arm does not cut the pass's last call into two row ranges (VP_OPT_ROW_BEGIN/_END "
                          "+ VP_FLAG_GATHER_ONLY) whose first half is all-reduced under the second half's gather.  Either way the "
@@ -585,6 +588,13 @@ def main():
 
     import voxproj_host
     from synthetic_scene import make_features_torch, make_scene
+    if a.one_view_gather >= 0:
+        voxproj_host.set_default_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view_gather)
+        try:
+            import project_features_cuda as _m
+            _m.set_workspace_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view_gather)
+        except ImportError:
+            pass
 
     if a.workload == "R4":
         return bench_colors(a, dev, rank, world, dist)
