@@ -670,7 +670,7 @@ def main():
         from aggregate_voxel_features_onthefly import VoxelFeatureAggregator
         from view_sharding import split_point
         agg = VoxelFeatureAggregator(torch.from_numpy(scene.occ), scene.grid_origin.astype(np.float64), scene.voxel_size, C, "fast", dev)
-        assert agg.n_rows == n_rows and agg._opts(W, H) == opts
+        assert agg.n_rows == n_rows and np.array_equal(np.asarray(agg._opts(W, H), np.float32), np.asarray(opts, np.float32))
         if a.heavy_threshold > 0:
             agg.ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, a.heavy_threshold)
         if a.march_lds_kb >= 0:
