@@ -11,6 +11,10 @@ oracle's float64 accumulation, per element, relative to that voxel row's own mag
 relative per element wherever the element is not a cancellation residue (|sum| >= 1 % of the row's magnitude).
 RGB: float32 colour sums, view counts, first views and pixel indices bit-exact.
 """
+import importlib.util
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +23,20 @@ from synthetic_scene import make_features_torch, make_scene
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_module():
+    """bench.py as a module (its call plan is what these tests must run, not a copy of it)."""
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    return m
 
 
 def _feature_config(oracle_mod, n_vox, n_views_scene, W, H, C, views, min_heavy):
@@ -113,14 +131,18 @@ def test_config5_rgb_500k_voxels_eight_views_vs_oracle(oracle_mod):
 
 
 def test_config3_full_300_view_pipelined_pass_counts_vs_oracle(oracle_mod):
-    # The WHOLE metric workload the way bench.py drives it -- 300 views, 32 per pipelined call, production heavy-voxel
-    # threshold, a pool of 32 resident maps cycled -- against the oracle's ray-march of all 300 views: per-voxel pixel
+    # The WHOLE metric workload the way bench.py drives it -- 300 views cut into calls by bench.plan_calls itself (today:
+    # five pipelined calls of 60 views, 65 GB of maps resident, heavy threshold 256 + 64 * 60 = 4096 pixels), production
+    # heavy-voxel threshold, the resident pool cycled -- against the oracle's ray-march of all 300 views: per-voxel pixel
     # counts and per-voxel view counts bit-exact.  The feature sums (326 GB of rows) cannot be replayed on the host; they
     # are checked through a checksum of checksums: per channel, the sum over all voxel rows must equal the sum of the
-    # rows of all hit pixels, evaluated independently in float64 from the ORACLE's first-hit images.
+    # rows of all hit pixels, evaluated independently in float64 from the ORACLE's first-hit images.  (The per-row check
+    # of one such call is test_config3_one_bench_sized_call_rows_vs_float64_reference below.)
     import voxproj_host
     dev = torch.device(DEV)
-    n_vox, n_views, W, H, C, chunk = 200000, 300, 968, 548, 512, 32
+    n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
+    chunk, n_calls, resident = _bench_module().plan_calls(n_views, H, W, C, 4)
+    assert chunk * n_calls >= n_views and resident == chunk            # one call's worth of maps, cycled
     s = make_scene(n_vox, n_views, W, H, seed=0)
     n_rows = n_vox + 1
     occ64 = s.occ[None].astype(np.int64)
@@ -147,16 +169,17 @@ def test_config3_full_300_view_pipelined_pass_counts_vs_oracle(oracle_mod):
     views_ref = np.zeros(n_rows, np.int64)
     tot = torch.zeros(C, dtype=torch.float64, device=dev)
     tot_abs = torch.zeros(C, dtype=torch.float64, device=dev)
-    for a in range(0, n_views, chunk):
-        b = min(n_views, a + chunk)
+    sub = 20                                                  # oracle views per batch (host memory: 4 bytes per pixel)
+    for a in range(0, n_views, sub):
+        b = min(n_views, a + sub)
         hits = oracle_mod.first_hit(occ64, s.c2w[a:b].reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, 1, b - a)
         count_ref += np.bincount(hits.reshape(-1), minlength=n_rows)
         for v in range(b - a):
             ids = np.unique(hits[0, v])
             views_ref[ids[ids > 0]] += 1
-        mask = torch.from_numpy(hits[0] > 0).to(dev)                      # [v,H,W]: view a+v reads pool slot v
+        mask = torch.from_numpy(hits[0] > 0).to(dev)                      # [v,H,W]: view a+v reads pool slot (a+v) % chunk
         for v in range(b - a):
-            rows = pool[0, v][mask[v]].double()
+            rows = pool[0, (a + v) % chunk][mask[v]].double()
             tot += rows.sum(0)
             tot_abs += rows.abs().sum(0)
     count_ref[0] = 0
@@ -164,3 +187,76 @@ def test_config3_full_300_view_pipelined_pass_counts_vs_oracle(oracle_mod):
     assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
     assert int(count_ref.sum()) > 0.99 * n_views * H * W
     assert ((out_t.double().sum(0) - tot).abs() <= 1e-6 * tot_abs).all()
+
+
+def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
+    """ONE call of the size bench.py plans for the metric workload (60 views of 968x548x512, heavy threshold 4096 pixels,
+    voxels of up to ~9 k pixels in the call) checked ROW BY ROW against a reference that no HIP gather touched: the ORACLE's
+    first-hit images (CPU) and, per view, index_add_ of the hit pixels' rows in float64 on the device (torch).  Every voxel
+    row -- the one-wavefront ones and the heavy ones summed by a workgroup -- within 1e-4 of the float64 sums relative to
+    the row's magnitude, and per element wherever the element is not a cancellation residue; pixel counts and view counts
+    exact.  (VERDICT r3 weak #8: at this call size the sums used to be compared with another HIP run only.)"""
+    import voxproj_host
+    dev = torch.device(DEV)
+    n_vox, n_views, W, H, C = 200000, 300, 968, 548, 512
+    V, n_calls, _ = _bench_module().plan_calls(n_views, H, W, C, 4)
+    assert V >= 32
+    s = make_scene(n_vox, n_views, W, H, seed=0)
+    n_rows = n_vox + 1
+    occ64 = s.occ[None].astype(np.int64)
+    feats = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    occ_t, intr_t = torch.from_numpy(occ64).to(dev), torch.from_numpy(s.intr[None]).to(dev)
+    opts, origin = [float(v) for v in s.opts()], [float(v) for v in s.grid_origin]
+    ws = voxproj_host.Workspace()
+
+    def call(ci):
+        views = list(range(ci * V, min(n_views, (ci + 1) * V)))
+        count_t.zero_(); views_t.zero_(); out_t.zero_()
+        voxproj_host.project_features_raw(feats[:, :len(views)], occ_t, torch.from_numpy(s.c2w[views]).reshape(-1).contiguous().to(dev),
+                                          intr_t, opts, count_t, out_t, origin, s.voxel_size, workspace=ws, sync=True, views_hit=views_t)
+        c = voxproj_host.counters(ws, dev)
+        assert c["bad_id"] == 0 and c["box_miss"] == 0
+        return views, c
+
+    # the call of the bench's pass with the most heavy voxels (all of them read the same resident maps)
+    heavy_per_call = [call(ci)[1]["n_heavy"] for ci in range(n_calls)]
+    views, ctr = call(int(np.argmax(heavy_per_call)))
+    assert len(views) == V and ctr["n_heavy"] == max(heavy_per_call) > 0, heavy_per_call
+    # the reference: oracle march -> float64 scatter-add on the device, view by view
+    ref = torch.zeros(n_rows, C, dtype=torch.float64, device=dev)
+    count_ref = np.zeros(n_rows, np.int64)
+    views_ref = np.zeros(n_rows, np.int64)
+    sub = 20
+    for a in range(0, V, sub):
+        b = min(V, a + sub)
+        hits = oracle_mod.first_hit(occ64, s.c2w[views[a:b]].reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, 1, b - a)
+        count_ref += np.bincount(hits.reshape(-1), minlength=n_rows)
+        for v in range(b - a):
+            ids_np = np.unique(hits[0, v])
+            views_ref[ids_np[ids_np > 0]] += 1
+            ids = torch.from_numpy(hits[0, v].reshape(-1).astype(np.int64)).to(dev)
+            rows = feats[0, a + v].reshape(-1, C).double()
+            ref.index_add_(0, ids, rows)
+            del rows
+    count_ref[0] = 0
+    got_c = count_t.cpu().numpy().astype(np.int64)
+    assert np.array_equal(got_c, count_ref) and np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
+    heavy_t = 256 + 64 * V
+    heavy = torch.from_numpy(count_ref > heavy_t).to(dev)
+    assert ctr["n_heavy"] == int(heavy.sum().item()) > 0 and int(count_ref.max()) > heavy_t
+    ref[0] = 0
+    err = (out_t.double() - ref).abs()
+    row_mag = ref.abs().max(dim=1, keepdim=True).values
+    touched = torch.from_numpy(count_ref > 0).to(dev)
+    assert float(out_t[~touched].abs().max().item()) == 0.0                 # untouched rows stay untouched
+    rel_row = (err[touched] / row_mag[touched])
+    assert float(rel_row.max().item()) <= 1e-4, float(rel_row.max().item())
+    solid = touched[:, None] & (ref.abs() >= 1e-2 * row_mag)
+    rel_el = err[solid] / ref.abs()[solid]
+    assert float(rel_el.max().item()) <= 1e-4, float(rel_el.max().item())
+    # and the heavy rows on their own (the workgroup role's fixed summation tree)
+    assert float((err[heavy] / row_mag[heavy]).max().item()) <= 1e-4
