@@ -362,7 +362,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // VP_OPT_ONE_VIEW_GATHER = n > 0 overrides it.
         ProfSpan sp; sp.begin(2, s0);
         const int per_cu = rec.opt_one_view > 0 ? (int)std::min<long long>(rec.opt_one_view, 256) : 16;
-        const long long want = (long long)device_cus() * per_cu;
+        // (values from 1000 on: a grid of exactly n - 1000 workgroups -- tests walk the batches of 64 entries per wavefront)
+        const long long want = rec.opt_one_view >= 1000 ? rec.opt_one_view - 1000 : (long long)device_cus() * per_cu;
         const long long cap = (n_rows - 1 + 3) / 4;           // never more wavefronts than voxel IDs
         const unsigned nblk = (unsigned)std::max<long long>(1, std::min(want, cap));
         g.heavy_blocks = heavy_t != 2147483647 ? (int)std::min<unsigned>(HEAVY_BLOCKS, nblk) : 0;

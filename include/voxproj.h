@@ -296,7 +296,7 @@ int vp_workspace_release(void *workspace);
  *                           voxel is summed by the same kernel role -- to the same bits -- as in the unsplit call
  *   VP_OPT_ONE_VIEW_GATHER  0 = calls of ONE view (B*V == 1) go through the general gather kernel instead of the one-view
  *                           kernel (A/B arm; same results bit for bit); n > 0 = the one-view kernel with n workgroups per CU
- *                           (default 16); < 0 restores the default
+ *                           (default 16; 1000 + g: exactly g workgroups, a test hook); < 0 restores the default
  */
 enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2, VP_OPT_ROW_BEGIN = 3, VP_OPT_ROW_END = 4, VP_OPT_ONE_VIEW_GATHER = 5 };
 int vp_workspace_set_option(void *workspace, int option, long long value);
