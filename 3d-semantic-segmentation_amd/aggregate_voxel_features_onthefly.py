@@ -371,14 +371,25 @@ class FeatureFeeder:
         pinned = [None] * nbuf        # uint8 staging buffers, grown on demand
         copied = [None] * nbuf        # event of the last H2D copy that read each buffer
 
-        def read_piece(fd, view, off, file_off, n):
+        def read_piece(path, fd, view, off, file_off, n):
             done = 0
             while done < n:           # preadv may return short
                 got = os.preadv(fd, [view[off + done:off + n]], file_off + done)
                 if got <= 0:
-                    raise IOError("unexpected end of file")
+                    raise IOError(f"{path}: unexpected end of file at byte {file_off + done} (its header promises {file_off - off + len(view)} bytes or more)")
                 done += got
             return n
+
+        def close_file(fd, futs):
+            """Close a file only when none of its piece reads can still be inside preadv on it (the descriptor's number may be
+            handed to the next os.open at once: a straggler would read another file's bytes into the staging buffer)."""
+            if fd is None:
+                return
+            for f in futs:
+                f.cancel()
+            from concurrent.futures import wait
+            wait(futs)
+            os.close(fd)
 
         def submit(pool, i):
             """Queue the reads of file i: (layout, buffer slot, fd, [future per piece]) -- or a whole-array fallback."""
@@ -395,39 +406,47 @@ class FeatureFeeder:
                 pinned[b] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
             view = memoryview(pinned[b].numpy())
             fd = os.open(self.paths[i], os.O_RDONLY)
-            futs = [pool.submit(read_piece, fd, view, o, off0 + o, min(self.CHUNK, nbytes - o)) for o in range(0, nbytes, self.CHUNK)]
+            futs = [pool.submit(read_piece, self.paths[i], fd, view, o, off0 + o, min(self.CHUNK, nbytes - o)) for o in range(0, nbytes, self.CHUNK)]
             return (shape, dtype, nbytes), b, fd, futs
 
         copy_stream = torch.cuda.Stream(self.dev, priority=-1)     # a queue of its own (see _to_device_ready)
         with ThreadPoolExecutor(max_workers=self.io_threads) as pool:
-            pending = [submit(pool, i) for i in range(min(self.depth, len(self.paths)))]
-            for i, p in enumerate(self.paths):
-                lay, b, fd, futs = pending.pop(0)
-                with torch.cuda.stream(copy_stream):
-                    if lay is None:
-                        host = torch.from_numpy(futs[0].result())
-                        d = host.to(self.dev)                    # pageable: blocking, rare path
-                    else:
-                        shape, dtype, nbytes = lay
-                        raw = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.dev)
-                        o = 0
-                        try:
-                            for f in futs:                       # in order: the bus follows the readers piece by piece
-                                n = f.result()
-                                raw[o:o + n].copy_(pinned[b][o:o + n], non_blocking=True)
-                                o += n
-                        finally:
-                            os.close(fd)
-                        d = raw[:nbytes].view(getattr(torch, np.dtype(dtype).name)).reshape(shape)
-                    ev = torch.cuda.Event()
-                    ev.record(copy_stream)
-                copied[b] = ev
-                if i + self.depth < len(self.paths):             # submitted only now: its buffer's previous copy is recorded
-                    pending.append(submit(pool, i + self.depth))
-                cur = torch.cuda.current_stream(self.dev)
-                cur.wait_event(ev)
-                d.record_stream(cur)                             # allocated on the copy stream, consumed on this one
-                yield i, p, d
+            pending = []
+            try:
+                pending = [submit(pool, i) for i in range(min(self.depth, len(self.paths)))]
+                for i, p in enumerate(self.paths):
+                    lay, b, fd, futs = pending.pop(0)
+                    with torch.cuda.stream(copy_stream):
+                        if lay is None:
+                            host = torch.from_numpy(futs[0].result())
+                            d = host.to(self.dev)                    # pageable: blocking, rare path
+                        else:
+                            shape, dtype, nbytes = lay
+                            raw = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.dev)
+                            o = 0
+                            try:
+                                for f in futs:                       # in order: the bus follows the readers piece by piece
+                                    n = f.result()
+                                    raw[o:o + n].copy_(pinned[b][o:o + n], non_blocking=True)
+                                    o += n
+                            finally:
+                                close_file(fd, futs)
+                            d = raw[:nbytes].view(getattr(torch, np.dtype(dtype).name)).reshape(shape)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                    copied[b] = ev
+                    if i + self.depth < len(self.paths):             # submitted only now: its buffer's previous copy is recorded
+                        pending.append(submit(pool, i + self.depth))
+                    cur = torch.cuda.current_stream(self.dev)
+                    cur.wait_event(ev)
+                    d.record_stream(cur)                             # allocated on the copy stream, consumed on this one
+                    yield i, p, d
+            finally:
+                # the consumer stopped early (an exception on its side, a break) or a file failed: the files read ahead are
+                # still open, their reads may still be running
+                for _, _, fd, futs in pending:
+                    close_file(fd, futs)
+                copy_stream.synchronize()                            # the staging buffers outlive the copies that read them
 
 
 def _image_size(entry, cams, images_dir, name):

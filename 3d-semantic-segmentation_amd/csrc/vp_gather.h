@@ -243,7 +243,7 @@ constexpr long long GATHER_G32_SMALL_IMAGE = 262144;     // pixels per view up t
 // Output rows are read once and written once per call by the wavefront that owns the voxel: no reuse inside a launch.
 // The finished row is stored WRITE-THROUGH (buffer_store_dwordx4 with the sc0 sc1 cache-policy bits): stores that leave
 // dirty lines in L2 cost this read-bound kernel far more than their bytes, and on some (feature pool, output rows)
-// placement pairs several times more (tools/probe_stores.py: +3.9 % per launch for one plain 2-KiB store per 272 rows
+// placement pairs several times more (profiles/r03_probe_row_stores_microbenchmark.log: +3.9 % per launch for one plain 2-KiB store per 272 rows
 // read, +12.7 % on a bad pair; +2.3 % / +4.6 % written through; the same through uncached memory or a non-temporal store).
 // In the gather itself: -0.3 ... -1.5 % per launch (profiles/r03_ab_output_row_store_policy.log).  The row's load stays a
 // plain load (a non-temporal load of the row was measured slower).  Visibility is that of a plain store: the line goes
@@ -380,13 +380,7 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
     for (int cb = 0; cb < C; cb += CB) {
         Acc<K, VEC> acc;
         float *orow = g.out + (long long)id * C + cb;
-#if defined(VP_DIAG_NOLOAD)
-        // timing experiment only (tools/probe_levels_rr.py): start from zero instead of the output row -- WRONG sums
-#pragma unroll
-        for (int i_ = 0; i_ < K * VEC; i_++) acc.a[i_] = 0.f;
-#else
         acc_load<K, VEC>(acc, orow, cb, C, lane);
-#endif
         const Acc<K, VEC> acc0 = acc;
         int found = 0, nviews = 0;
         for (int b = 0; b < p.B && found < expected; b++) {
@@ -458,9 +452,6 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
                 nviews += found > before;
             }
         }
-#if defined(VP_DIAG_NOSTORE)
-        if (found == -12345)        // timing experiment only: never true, keeps the sums alive -- outputs are NOT written
-#endif
         acc_store<K, VEC, WT>(acc, orow, cb, C, lane);
         if (cb == 0 && lane == 0) {
             g.count[id] += found;   // K.cu:77 (one add of the per-call total)

@@ -557,7 +557,7 @@ class _ContiguousDeviceMemory:
 def resident_empty(shape, dtype, device, fallback=True, flags=0x4):
     """An uninitialised CUDA tensor for a long-lived, heavily gathered buffer (the resident feature maps, the output rows)
     in PHYSICALLY CONTIGUOUS device memory (hipExtMallocWithFlags, hipDeviceMallocContiguous).  An experiment on the
-    placement spread of DESIGN.md section 4 (tools/probe_contig.py): inside one process a 17 GB pool re-allocated this way
+    placement spread of DESIGN.md section 4 (round 2's probe, in git history): inside one process a 17 GB pool re-allocated this way
     kept one speed level (2.700-2.705 ms per 16-view launch, against 2.72-3.09 ms over plain re-allocations), but a 35 GB
     pool showed no difference and the spread between processes stayed -- so nothing uses it by default (bench.py --alloc
     contiguous).  With ``fallback`` a failed contiguous allocation (no contiguous range that large) falls back to torch's

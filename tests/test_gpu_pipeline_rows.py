@@ -613,3 +613,38 @@ def test_feature_feeder_delivers_every_map_in_order(tmp_path):
         assert len(seen) == len(paths)
         for a, b in zip(arrays, seen):
             assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_feature_feeder_closes_its_files_on_errors_and_early_exits(tmp_path):
+    # a truncated map surfaces as an IOError that NAMES the file; whether the feeder ends by exhaustion, by the
+    # consumer breaking out or by an error, no descriptor of a read-ahead file stays open
+    from aggregate_voxel_features_onthefly import FeatureFeeder
+    rng = np.random.default_rng(19)
+    paths = []
+    for i in range(8):
+        p = tmp_path / f"f{i:02d}.npy"
+        np.save(p, rng.standard_normal((8, 40, 50)).astype(np.float32))
+        paths.append(str(p))
+    short = tmp_path / "f03.npy"
+    data = short.read_bytes()
+    short.write_bytes(data[:len(data) // 2])                              # the header promises twice the bytes
+
+    def open_fds():
+        return {os.readlink(f"/proc/self/fd/{n}") for n in os.listdir("/proc/self/fd") if os.path.exists(f"/proc/self/fd/{n}")}
+
+    before = {f for f in open_fds() if str(tmp_path) in f}
+    feeder = FeatureFeeder(paths, DEV, depth=3, io_threads=3)
+    feeder.CHUNK = 8192
+    got = []
+    with pytest.raises(IOError, match="f03.npy"):
+        for i, p, t in feeder:
+            got.append(i)
+    assert got == [0, 1, 2]
+    assert {f for f in open_fds() if str(tmp_path) in f} == before
+    short.write_bytes(data)
+    for i, p, t in FeatureFeeder(paths, DEV, depth=4, io_threads=2):      # the consumer walks away after two maps
+        if i == 1:
+            break
+    import gc
+    gc.collect()
+    assert {f for f in open_fds() if str(tmp_path) in f} == before
