@@ -122,6 +122,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // so that a later gather-only call cannot match the call before the failed one
     WsState *st = ws_state(workspace, true);
     struct HitGuard { WsState *st; bool keep; ~HitGuard() { if (!keep) st->has_hit = false; } } hit_guard{st, false};
+    if (!sticky_open(*st)) return fail(VP_EHIP, "could not allocate the workspace record's page of pinned host memory (sticky error words)");
     if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || C <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0 || n_rows <= 0)
         return fail(VP_EINVAL, "non-positive dimension");
     if ((long long)B * V > 65535) return fail(VP_EINVAL, "B*V = %lld exceeds 65535", (long long)B * V);
@@ -219,12 +220,12 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         rec.opened = true;
     }
     if (verify && rec_matches && rec.copy_valid) {
-        int differs = 1;
-        VP_HIP(hipMemsetAsync(status + ST_OCCDIFF, 0, sizeof(int), s0));
-        hipLaunchKernelGGL(k_occ_compare_copy, dim3(cmp_blocks), dim3(256), 0, s0, (const long long *)occ, occ_copy, cells * B, status + ST_OCCDIFF);
-        VP_HIP(hipMemcpyAsync(&differs, status + ST_OCCDIFF, sizeof(int), hipMemcpyDeviceToHost, s0));
+        // the verdict comes back through the record's page of pinned host memory (no memset, no device-to-host copy)
+        volatile int *differs = rec.sticky_host + ST_OCCDIFF;
+        *differs = 0;
+        hipLaunchKernelGGL(k_occ_compare_copy, dim3(cmp_blocks), dim3(256), 0, s0, (const long long *)occ, occ_copy, cells * B, rec.sticky_dev + ST_OCCDIFF);
         VP_HIP(hipStreamSynchronize(s0));
-        rebuild = differs != 0;      // the copy is already up to date either way
+        rebuild = *differs != 0;      // the copy is already up to date either way
     } else if (rebuild) {
         if (verify) {
             // first checked call on this workspace / new shape: take the copy now
@@ -298,14 +299,14 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         ProfSpan sp; sp.begin(0, s1);
         // one launch clears the per-call status words and the per-call histogram, and checks the workspace header
         hipLaunchKernelGGL(k_zero_call, dim3((unsigned)((n_rows + 1023) / 1024)), dim3(256), 0, s1, status, cnt_call, (long long)n_rows,
-                           (const int *)status0, status0, WS_MAGIC, rec.gen, expect_tables);
+                           status0, rec.sticky_dev, WS_MAGIC, rec.gen, expect_tables);
         sp.end();
     }
     if (!gather_only) {
         FirstHitArgs fa;
         fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
         fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
-        fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status; fa.sticky = (int *)(ws + l.status[0]);
+        fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status; fa.sticky = rec.sticky_dev;
         const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
         ProfSpan sp; sp.begin(1, s1);
         if (flags & VP_FLAG_EXACT_MARCH) {
@@ -462,29 +463,22 @@ int vp_stream_read(const float *src, int64_t n_floats, float *sink, void *stream
 // would fail the next, valid blocking call); otherwise ONE condition per read, only the reported word is cleared.
 static int workspace_status_impl(void *workspace, void *stream_, bool drain_all)
 {
+    static_assert(ST_WORDS * sizeof(int) == 256, "a status block -- and the record's sticky page -- is one 256-byte slot");
     if (!workspace) return fail(VP_EINVAL, "null workspace");
-    static_assert(ST_WORDS * sizeof(int) == 256, "status block is one 256-byte slot");
-    static_assert(ST_STICKY_STUCK == ST_STICKY_BADID + 1 && ST_STICKY_BADID >= ST_CALL_WORDS, "sticky words sit behind the per-call ones");
-    int st[2 * ST_WORDS];
-    int rc = read_status(workspace, (hipStream_t)stream_, st);
-    if (rc != VP_OK) return rc;
     WsState *rec = ws_state(workspace, false);
-    if (!rec || !rec->opened) return VP_OK;   // no call has run on this workspace yet
-    // the sticky words mean something only in memory that carries this record's header: anything else (freed and handed out
-    // again, overwritten, and no call has looked at it since) reads back as garbage -- the next call's k_zero_call reports it
-    if ((unsigned)st[ST_HDR_MAGIC] != WS_MAGIC || (unsigned)st[ST_HDR_GEN] != rec->gen) return VP_OK;
+    // everything queued on the workspace's streams has run when this returns: the side stream first (its work feeds the caller's)
+    if (rec && rec->pipe.ok) VP_HIP(hipStreamSynchronize(rec->pipe.side));
+    VP_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    if (!rec || !rec->opened || !rec->sticky_host) return VP_OK;   // no call has run on this workspace yet
     // the sticky words collect the errors of EVERY call since the last read (the per-call words of a buffer set are cleared
-    // when the set is reused two pipelined calls later)
-    const int stale = st[ST_STICKY_STALE], stuck = st[ST_STICKY_STUCK], badid = st[ST_STICKY_BADID];
+    // when the set is reused two pipelined calls later).  They live in the record's own page of pinned host memory, written
+    // by the kernels through its device mapping: nothing to copy, and nobody else's to overwrite
+    volatile int *sw = rec->sticky_host;
+    const int stale = sw[ST_STICKY_STALE], stuck = sw[ST_STICKY_STUCK], badid = sw[ST_STICKY_BADID];
     const int word = stale ? ST_STICKY_STALE : stuck ? ST_STICKY_STUCK : badid ? ST_STICKY_BADID : -1;
     if (word >= 0) {
-        if (drain_all) {
-            static_assert(ST_STICKY_STALE + 2 == ST_STICKY_STUCK, "the three sticky words are contiguous");
-            VP_HIP(hipMemsetAsync((int *)workspace + ST_STICKY_STALE, 0, 3 * sizeof(int), (hipStream_t)stream_));
-        } else {
-            VP_HIP(hipMemsetAsync((int *)workspace + word, 0, sizeof(int), (hipStream_t)stream_));
-        }
-        VP_HIP(hipStreamSynchronize((hipStream_t)stream_));
+        if (drain_all) sw[ST_STICKY_STALE] = sw[ST_STICKY_STUCK] = sw[ST_STICKY_BADID] = 0;
+        else sw[word] = 0;
     }
     const char *also = !drain_all ? "" : (word == ST_STICKY_STALE && (stuck || badid)) ? " (also pending, now cleared: stuck rays and/or out-of-range IDs)"
                                         : (word == ST_STICKY_STUCK && badid) ? " (also: a ray hit an occupancy ID outside [1, n_rows))" : "";

@@ -95,7 +95,12 @@ struct WsState {
     long long n_rows = 0;
     bool copy_valid = false;
     long long builds = 0;
-    bool opened = false;              // k_ws_open has run for this record (header + sticky words initialised)
+    bool opened = false;              // k_ws_open has run for this record (header initialised)
+    // Sticky error words of the workspace (ST_STICKY_*): a page of pinned HOST memory that the kernels write through its
+    // device mapping and vp_workspace_status reads after synchronising -- no device-to-host copy at the end of a blocking
+    // call (round 4: ~8 us of a 0.3-ms drop-in call), and the words belong to the record, not to workspace memory that
+    // someone else may have scribbled over
+    int *sticky_host = nullptr, *sticky_dev = nullptr;
     // options (vp_workspace_set_option); -1 = the library's default
     long long opt_heavy_t = -1;
     long long opt_march_lds_kb = -1;
@@ -153,6 +158,7 @@ void ws_forget(const void *workspace)
         g_ws.erase(it);
     }
     pipe_destroy(st->pipe);
+    if (st->sticky_host) (void)hipHostFree(st->sticky_host);
     delete st;
 }
 
@@ -170,6 +176,19 @@ int device_cus()
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
     cus[dev] = n;
     return n;
+}
+
+// the record's page of sticky error words (pinned, mapped into every device's address space), allocated on first use
+bool sticky_open(WsState &st)
+{
+    if (st.sticky_host) return true;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 256, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+    memset(h, 0, 256);      // ST_WORDS ints (the enum follows below)
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
+    st.sticky_host = (int *)h;
+    st.sticky_dev = (int *)d;
+    return true;
 }
 
 bool pipe_open(PipeState &ps)
@@ -205,9 +224,10 @@ struct Params {
 };
 
 // Status block (one 256-byte slot per buffer set).  Words [0, ST_CALL_WORDS) are per call: cleared when a call starts
-// on the set, read by vp_workspace_counters.  ST_STICKY_* live in the block of set 0 only, are raised together with
-// their per-call twins, survive every later call on the workspace and are cleared by vp_workspace_status alone --
-// so an error raised by pipelined call j is still there when the job finally asks, however many calls later.
+// on the set, read by vp_workspace_counters.  ST_STICKY_* index the record's page of pinned host memory (WsState::sticky_*),
+// are raised together with their per-call twins, survive every later call on the workspace and are cleared by
+// vp_workspace_status alone -- so an error raised by pipelined call j is still there when the job finally asks, however
+// many calls later.
 // ST_HDR_*: the workspace header (set 0 only): magic, the generation of the record that initialised this memory, the key
 // of the tables it holds (0 while none are sealed) -- written by k_ws_open / k_ws_seal, compared by every call's k_zero_call.
 enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_ZERO = 3 /* never written */, ST_STUCK = 4, ST_OCCDIFF = 5, ST_STALE = 6,

@@ -38,7 +38,7 @@ struct FirstHitArgs {
     int *heavy_list;
     int heavy_t;
     int *status;
-    int *sticky;   // status block of set 0: ST_STICKY_* words (never cleared by a call)
+    int *sticky;   // the workspace record's sticky error words (pinned host memory, device mapping; never cleared by a call)
 };
 
 template <int MODE>
@@ -92,7 +92,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     // ulp(t) <= ulp(tEnd), so it does iff adding inc changes tEnd.  Such a ray is reported, not marched.
     if ((t < tEnd) && !(tEnd + p.inc > tEnd)) {
         atomicOr(&status[ST_STUCK], 1);
-        atomicOr(&fa.sticky[ST_STICKY_STUCK], 1);
+        *(volatile int *)&fa.sticky[ST_STICKY_STUCK] = 1;      // a plain store of the constant: host memory, no atomic needed
         t = tEnd;
     }
     if constexpr (!ACCEL) {
@@ -219,7 +219,7 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
     }
     if (id != 0 && (id < 0 || id >= p.n_rows)) {   // the reference would write out of bounds here
         atomicOr(&status[ST_BADID], 1);
-        atomicOr(&fa.sticky[ST_STICKY_BADID], 1);
+        *(volatile int *)&fa.sticky[ST_STICKY_BADID] = 1;
         id = 0;
     }
     hit[((long long)bv * p.height + y) * p.width + x] = id;

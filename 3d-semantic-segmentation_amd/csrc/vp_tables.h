@@ -176,7 +176,7 @@ __global__ void k_ws_seal(int *status0, unsigned tables) { status0[ST_HDR_TABLES
 // stale: k_first_hit then does nothing (so neither does the gather: the histogram stays zero) and the sticky word makes
 // vp_workspace_status report it.
 __global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int *__restrict__ cnt_call, long long n_rows,
-                                                   const int *hdr, int *sticky, unsigned magic, unsigned gen, unsigned tables)
+                                                   int *hdr, int *sticky, unsigned magic, unsigned gen, unsigned tables)
 {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (blockIdx.x == 0 && threadIdx.x < ST_CALL_WORDS) {
@@ -186,13 +186,11 @@ __global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int
             if (!mine || (unsigned)hdr[ST_HDR_TABLES] != tables) {
                 v = 1;
                 if (!mine) {
-                    // not this record's words: garbage.  The block becomes this record's from here on -- with "no tables" in
-                    // the header, so every later call that trusts tables is stale too -- and vp_workspace_status, which
-                    // believes sticky words only under its own record's header, reports the condition
-                    sticky[ST_STICKY_BADID] = 0; sticky[ST_STICKY_STUCK] = 0;
-                    sticky[ST_HDR_MAGIC] = (int)magic; sticky[ST_HDR_GEN] = (int)gen; sticky[ST_HDR_TABLES] = 0;
+                    // not this record's memory (any more): the block becomes this record's from here on, with "no tables" in
+                    // the header, so every later call that trusts tables is stale too
+                    hdr[ST_HDR_MAGIC] = (int)magic; hdr[ST_HDR_GEN] = (int)gen; hdr[ST_HDR_TABLES] = 0;
                 }
-                sticky[ST_STICKY_STALE] = 1;
+                *(volatile int *)&sticky[ST_STICKY_STALE] = 1;
             }
         }
         status[threadIdx.x] = v;

@@ -134,7 +134,6 @@ def parse():
 
 
 PMC_PROFILE = "r04_pmc_traffic.json"           # the round's committed counter passes (tools/profile_round.sh writes it)
-PMC_VIEWS_PER_CALL = {"f32": 60, "f16": 100}     # what tools/profile_round.sh passes as --chunk: plan_calls' default for R2
 
 
 def source_digest():
@@ -150,7 +149,7 @@ def source_digest():
 
 
 def pmc_traffic(workload, chunk, dtype):
-    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json),
+    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/<PMC_PROFILE>),
     corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
     None unless the profile was taken on this workload / views-per-call / dtype AND with these very kernel sources
     (the file records the digest of csrc/ it was measured on: a stale profile yields null, not a wrong number)."""
@@ -160,45 +159,50 @@ def pmc_traffic(workload, chunk, dtype):
             prof = json.load(f)
     except OSError:
         return None
-    run = prof.get("runs", {}).get(dtype)
+    run = prof.get("runs", {}).get(f"{workload}_{dtype}")
     # the profile's launches may hold a few views more or fewer than this run's (the per-view figure is what is used)
-    vpc = (run or {}).get("views_per_call", prof.get("views_per_call", 0))
-    if run is None or prof.get("workload") != workload or abs(vpc - chunk) > 4:
+    if run is None or abs(run.get("views_per_call", 0) - chunk) > 4:
         return None
     if prof.get("source_digest") != source_digest():
         return None
     g = run["k_gather"]
-    return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / vpc
+    return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / run["views_per_call"]
+
+
+PMC_RUNS = {   # key: (directory suffix of tools/profile_round.sh, views per launch of that pass = plan_calls' default for the leg)
+    "R2_f32": ("f32", 60), "R2_f16": ("f16", 100), "R1_f32": ("R1", 50)}
 
 
 def write_pmc_json(prof_dir, out_path):
-    """profiles/r04_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
-    dtype), stamped with the digest of the kernel sources they were measured on."""
+    """profiles/<tag>_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
+    leg: R2 fp32, R2 fp16, R1 fp32), stamped with the digest of the kernel sources they were measured on."""
     import collections
     import csv
     import glob
     runs = {}
-    for dt in ("f32", "f16"):
+    for key, (sfx, vpc) in PMC_RUNS.items():
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for kind in ("fetch", "write"):
-            for f in glob.glob(os.path.join(prof_dir, f"{kind}_{dt}", "**", "*counter_collection.csv"), recursive=True):
+            for f in glob.glob(os.path.join(prof_dir, f"{kind}_{sfx}", "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     name = r["Kernel_Name"]
-                    k = "k_gather_heavy" if "k_gather_heavy" in name else "k_gather" if "k_gather" in name else \
+                    k = "k_gather_heavy" if "k_gather_heavy" in name else "k_gather_one" if "k_gather_one" in name else "k_gather" if "k_gather" in name else \
                         "k_first_hit" if "k_first_hit" in name else None
                     if k:
                         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if "k_gather" in per:
-            # full launches only (--views = two of them per pass; the pre-pass and the placement pass repeat them), at the
-            # views per launch the default plan gives that dtype: 60 (fp32) / 100 (fp16)
-            runs[dt] = {"views_per_call": PMC_VIEWS_PER_CALL[dt]}
-            runs[dt].update({k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), 1),
-                            "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]), 1)} for k, v in per.items()})
+        if "k_gather" in per and per["k_gather"].get("FETCH_SIZE") and per["k_gather"].get("WRITE_SIZE"):
+            # full launches only (two of them per pass; the pre-pass and the placement pass repeat them), at the views per
+            # launch the default plan gives that leg
+            runs[key] = {"views_per_call": vpc}
+            runs[key].update({k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), 1),
+                                  "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"])), 1)}
+                              for k, v in per.items() if v.get("FETCH_SIZE") and v.get("WRITE_SIZE")})
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --views 120 --chunk 60 | --views 200 --chunk 100 --dtype f16, MI355X (tools/profile_round.sh)",
+                     "--no-cpu-baseline --views 120 --chunk 60 | --views 200 --chunk 100 --dtype f16 | --workload R1, MI355X "
+                     "(tools/profile_round.sh)",
            "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane streaming reads -> doubled by the reader "
                    "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; units KB",
-           "workload": "R2", "views_per_call": 60, "source_digest": source_digest(), "runs": runs}
+           "source_digest": source_digest(), "runs": runs}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
     return doc

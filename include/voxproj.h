@@ -162,7 +162,9 @@ int vp_project_features_f16(const void *feats_f16, const int64_t *occ, const flo
                             void *stream, int flags);
 
 /*
- * Drains the workspace's streams, then reads back the sticky device-side error words of the workspace: they collect the
+ * Drains the workspace's streams (the library's side stream, then `stream`), then reads the sticky device-side error words of
+ * the workspace -- a page of pinned host memory owned by the library's record of the workspace, which the kernels write
+ * through its device mapping: no device-to-host copy, and nothing a stranger could have overwritten.  They collect the
  * errors (tables gone from recycled memory: VP_EINVAL; a ray parameter that cannot advance: VP_EINVAL; out-of-range ID:
  * VP_EBADID) of EVERY call made on the workspace since they were last reported, pipelined or not -- no later call erases
  * them.  One condition is reported per call, in that order, and only the reported one is cleared: call again (until

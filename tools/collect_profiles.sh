@@ -1,5 +1,5 @@
 #!/bin/bash
-tag=${1:-r03}
+tag=${1:-r04}
 # copies the summaries of tools/profile_round.sh $tag + tools/run_benches.sh (merged back under gpurun_out/) into profiles/
 P=profiles
 cp gpurun_out/${tag}_pmc_traffic.json $P/${tag}_pmc_traffic.json

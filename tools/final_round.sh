@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything profiles/ needs for a round, on the GPU box from the repo root: bash tools/final_round.sh r03
+# Everything profiles/ needs for a round, on the GPU box from the repo root: bash tools/final_round.sh r04
 # (GPU tests, rocprofv3 kernel trace + PMC traffic passes, every bench leg, the auxiliary benches).  Afterwards, in the build
-# container: bash tools/collect_profiles.sh r03
+# container: bash tools/collect_profiles.sh r04
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,7 +1,7 @@
 #!/bin/bash
-# every bench leg of the round, one JSON line each, into gpurun_out/<tag>_bench_*.log   (bash tools/run_benches.sh r03)
+# every bench leg of the round, one JSON line each, into gpurun_out/<tag>_bench_*.log   (bash tools/run_benches.sh r04)
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 o=gpurun_out
 python3 bench.py > $o/${tag}_bench_default.log 2>&1 || exit 1
 python3 bench.py --dtype f16 --no-cpu-baseline > $o/${tag}_bench_f16.log 2>&1 || exit 1
