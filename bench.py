@@ -827,6 +827,8 @@ def main():
             placement["ms_per_pass_after_timed_region"] = round((time.perf_counter() - t1) * 1e3, 3)
         reduced = {"checksum": float(ref_checksum.sum().item()), "checksum_abs": float(ref_abs.sum().item())}
 
+    ref_abs_all = 0.0
+
     def verify_reduced():
         # the aggregator's buffers hold the whole scene (on rank 0 after a reduce, everywhere after an all-reduce): the hit
         # counts must add up EXACTLY to the ranks' own (pre-pass) totals, and the feature sums, channel by channel, to the sum
@@ -835,6 +837,8 @@ def main():
         dist.all_reduce(t)
         chk = torch.stack([ref_checksum, ref_abs])
         dist.all_reduce(chk)
+        nonlocal ref_abs_all
+        ref_abs_all = float(chk[1].sum().item())
         if rank == 0 or a.collective == "allreduce":
             assert int(agg.count.sum().item()) == int(t.item()), "reduced hit counts do not add up to the ranks' totals"
             assert ((agg.sum32.double().sum(0) - chk[0]).abs() <= 1e-6 * chk[1] + 1e-9).all(), \
@@ -865,7 +869,13 @@ def main():
             arms[name[not default_split]] = {"ms_per_step": round(float(t[0].item()) / a.steps * 1e3, 3),
                                              "collective_ms_exposed": round(float(t[1].item()), 3)}
             if verify:
-                assert verify_reduced() == reduced, "the two collective arms left different scenes"
+                # each rank's own part is the same bits in both arms; the cross-rank sum may round differently (a collective
+                # over half the rows is chunked differently by the backend's ring), so: counts exactly, sums to fp32 rounding
+                other = verify_reduced()
+                if reduced:
+                    assert other["reduced_hit_pixels"] == reduced["reduced_hit_pixels"], "the two collective arms left different counts"
+                    assert abs(other["reduced_checksum"] - reduced["reduced_checksum"]) <= 1e-6 * float(ref_abs_all), \
+                        "the two collective arms left different scenes"
     split = default_split
 
     algo_local = hit_px * C * esize + touched * C * 4 * 2 + len(calls) * n_rows * 4 * 2 + len(my_views) * H * W * 4 * 2
