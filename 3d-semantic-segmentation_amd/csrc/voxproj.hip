@@ -122,7 +122,6 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // so that a later gather-only call cannot match the call before the failed one
     WsState *st = ws_state(workspace, true);
     struct HitGuard { WsState *st; bool keep; ~HitGuard() { if (!keep) st->has_hit = false; } } hit_guard{st, false};
-    if (!sticky_open(*st)) return fail(VP_EHIP, "could not allocate the workspace record's page of pinned host memory (sticky error words)");
     if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || C <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0 || n_rows <= 0)
         return fail(VP_EINVAL, "non-positive dimension");
     if ((long long)B * V > 65535) return fail(VP_EINVAL, "B*V = %lld exceeds 65535", (long long)B * V);
@@ -144,6 +143,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx, workspace_bytes);
     if (workspace_bytes < l.total) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, l.total);
     if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
+    // (every check above is host arithmetic; from here on the device is touched)
+    if (!sticky_open(*st)) return fail(VP_EHIP, "could not allocate the workspace record's page of pinned host memory (sticky error words)");
     char *ws = (char *)workspace;
     hipStream_t s0 = (hipStream_t)stream_;
 
