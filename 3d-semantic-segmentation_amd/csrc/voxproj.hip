@@ -75,10 +75,14 @@
         else hipLaunchKernelGGL((k_gather<4, 1, 4, MERGED, 1>), __VA_ARGS__);               \
     } while (0)
 
-// the one-view gather (vp_gather.h, k_gather_one)
-#define VP_DISPATCH_GATHER_ONE(VEC_OK, C, ...)                                    \
+// the one-view gather (vp_gather.h, k_gather_one).  SMALL: the view has few pixels (up to GATHER_G32_SMALL_IMAGE): a voxel gets
+// a handful of rows and the launch is bounded by the round trips per voxel, not by bandwidth -- 8 rows in flight per
+// wavefront instead of 4 (3 wavefronts per SIMD instead of 4): one R1 view 86.4 -> 75.5 us; one R2 view 225 -> 228 us, so
+// large views keep 4 (profiles/r04_one_view_gather.log)
+#define VP_DISPATCH_GATHER_ONE(SMALL, VEC_OK, C, ...)                             \
     do {                                                                          \
         if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather_one<1, 8, VP_F16_U>), __VA_ARGS__);    \
+        else if ((VEC_OK) && (C) > 256 && (SMALL)) hipLaunchKernelGGL((k_gather_one<2, 4, 8>), __VA_ARGS__); \
         else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather_one<2, 4, 4>), __VA_ARGS__); \
         else if (VEC_OK) hipLaunchKernelGGL((k_gather_one<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((k_gather_one<4, 1, 4>), __VA_ARGS__);                  \
@@ -369,7 +373,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         const long long cap = (n_rows - 1 + 3) / 4;           // never more wavefronts than voxel IDs
         const unsigned nblk = (unsigned)std::max<long long>(1, std::min(want, cap));
         g.heavy_blocks = heavy_t != 2147483647 ? (int)std::min<unsigned>(HEAVY_BLOCKS, nblk) : 0;
-        if (n_rows > 1) VP_DISPATCH_GATHER_ONE(vec_ok, C, dim3(nblk), dim3(256), 0, s0, g, p);
+        if (n_rows > 1) VP_DISPATCH_GATHER_ONE((long long)H * W <= GATHER_G32_SMALL_IMAGE, vec_ok, C, dim3(nblk), dim3(256), 0, s0, g, p);
         sp.end();
     }
     // (with VP_FLAG_SERIAL_SUMS no voxel can be heavy: the launch -- 5 us of a 0.1-ms one-view call -- is left out)
