@@ -105,23 +105,19 @@ __global__ __launch_bounds__(256) void k_block_dist(const unsigned long long *__
 
 // Near field: for every cell of every block within one block of an occupied block, the Chebyshev distance in
 // CELLS to the nearest occupied cell, capped at NEAR_CAP ("7 or more"), stored as three bit planes per 4x4x4 block
-// (NearRec, vp_common.h; nd == 0 <=> the cell is occupied).  One wavefront per block, one lane per cell; the shells
-// of radius 1, 2, ... around the cell are searched until one holds an occupied cell.
+// (NearRec, vp_common.h; nd == 0 <=> the cell is occupied).  One wavefront per block, one lane per cell.  An occupied cell
+// within 6 cells of a cell of this block lies in one of the 5x5x5 blocks around it: their 125 occupancy masks are fetched
+// in one round (two per lane), then walked in a wave-uniform loop -- empty blocks skipped, every set bit of the others
+// compared with all 64 cells at once (nine VALU instructions per occupied cell in the neighbourhood; the first version
+// searched shells of cells one dependent table read at a time and took 1.15 ms for R2 instead of 0.2).
 constexpr int NEAR_CAP = 7;
-
-__device__ __forceinline__ bool occ_bit(const unsigned long long *__restrict__ mask_b, int x, int y, int z,
-                                        int dimz, int dimy, int dimx, int nby, int nbx)
-{
-    if ((unsigned)x >= (unsigned)dimx || (unsigned)y >= (unsigned)dimy || (unsigned)z >= (unsigned)dimz) return false;
-    const unsigned long long m = mask_b[((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 2)];
-    return (m >> (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))) & 1ull;
-}
 
 __global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__restrict__ mask64,
                                                     const unsigned char *__restrict__ dist, NearRec *near2,
                                                     int dimz, int dimy, int dimx, int nbz, int nby, int nbx,
                                                     long long nblk, int B)
 {
+    (void)dimz; (void)dimy; (void)dimx;      // cells beyond the grid are never set in the masks
     const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const long long nreal = (long long)nbz * nby * nbx;
@@ -133,18 +129,33 @@ __global__ __launch_bounds__(256) void k_build_near(const unsigned long long *__
     int nd = NEAR_CAP;
     if (bd <= 1) {
         const int bz = blk / (nby * nbx), r = blk - bz * (nby * nbx), by = r / nbx, bx = r - by * nbx;
-        const int x = bx * 4 + (lane & 3), y = by * 4 + ((lane >> 2) & 3), z = bz * 4 + (lane >> 4);
-        if (occ_bit(mask_b, x, y, z, dimz, dimy, dimx, nby, nbx)) {
-            nd = 0;
-        } else {
-            for (int rad = 1; rad < NEAR_CAP && nd == NEAR_CAP; rad++)
-                for (int dz = -rad; dz <= rad && nd == NEAR_CAP; dz++)
-                    for (int dy = -rad; dy <= rad && nd == NEAR_CAP; dy++) {
-                        // the shell of radius rad: whole rows on its z and y faces, the two end cells of a row elsewhere
-                        const int step = (abs(dz) == rad || abs(dy) == rad) ? 1 : 2 * rad;
-                        for (int dx = -rad; dx <= rad; dx += step)
-                            if (occ_bit(mask_b, x + dx, y + dy, z + dz, dimz, dimy, dimx, nby, nbx)) { nd = rad; break; }
-                    }
+        // lane l holds the masks of neighbours l and 64 + l of the 5x5x5 neighbourhood (index = (dz+2)*25 + (dy+2)*5 + dx+2)
+        unsigned long long m_lo = 0ull, m_hi = 0ull;
+        {
+            const int i0 = lane, i1 = lane + 64;
+            const int z0 = bz + i0 / 25 - 2, y0 = by + (i0 / 5) % 5 - 2, x0 = bx + i0 % 5 - 2;
+            if ((unsigned)z0 < (unsigned)nbz && (unsigned)y0 < (unsigned)nby && (unsigned)x0 < (unsigned)nbx)
+                m_lo = mask_b[((long long)z0 * nby + y0) * nbx + x0];
+            if (i1 < 125) {
+                const int z1 = bz + i1 / 25 - 2, y1 = by + (i1 / 5) % 5 - 2, x1 = bx + i1 % 5 - 2;
+                if ((unsigned)z1 < (unsigned)nbz && (unsigned)y1 < (unsigned)nby && (unsigned)x1 < (unsigned)nbx)
+                    m_hi = mask_b[((long long)z1 * nby + y1) * nbx + x1];
+            }
+        }
+        // this lane's cell, in cells relative to the block's own corner
+        const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+        for (int i = 0; i < 125; i++) {
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(i < 64 ? m_lo : m_hi), i & 63);
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((i < 64 ? m_lo : m_hi) >> 32), i & 63);
+            unsigned long long m = ((unsigned long long)hi32 << 32) | lo32;
+            if (m == 0ull) continue;
+            const int ox = (i % 5 - 2) * 4, oy = ((i / 5) % 5 - 2) * 4, oz = (i / 25 - 2) * 4;      // the neighbour's corner
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int dx = abs(ox + (bit & 3) - cx), dy = abs(oy + ((bit >> 2) & 3) - cy), dz = abs(oz + (bit >> 4) - cz);
+                nd = min(nd, max(dx, max(dy, dz)));
+            }
         }
     }
     const unsigned long long p0 = __ballot(nd & 1), p1 = __ballot(nd & 2), p2 = __ballot(nd & 4);
