@@ -41,10 +41,20 @@ img = voxproj_host.hit_image(ws, dev).cpu().numpy().astype(np.int64)
 far, leap, fine = (img >> 20) & 1023, (img >> 10) & 1023, img & 1023
 print(f"{a.workload}, views {views}: per ray, mean (max)  far {far.mean():.2f} ({far.max()})  exact with a skip {leap.mean():.2f} ({leap.max()})  "
       f"exact one by one {fine.mean():.2f} ({fine.max()})  -> exact evaluations {(leap + fine).mean():.2f}, examined samples {(far + leap + fine).mean():.2f}")
+tot_ray = (far + leap + fine).reshape(-1)
+qs = [50, 75, 90, 95, 99, 99.9]
+print("examined samples per ray, percentiles " + ", ".join(f"{q}%: {np.percentile(tot_ray, q):.0f}" for q in qs) +
+      f";  share of all examined samples spent by rays with > 20: {tot_ray[tot_ray > 20].sum() / tot_ray.sum():.3f}, > 40: {tot_ray[tot_ray > 40].sum() / tot_ray.sum():.3f}"
+      f";  rays with > 20: {(tot_ray > 20).mean():.4f}")
+fine_ray = fine.reshape(-1)
+print("single steps next to geometry per ray, percentiles " + ", ".join(f"{q}%: {np.percentile(fine_ray, q):.0f}" for q in qs) +
+      f";  share of all single steps spent by rays with > 8 of them: {fine_ray[fine_ray > 8].sum() / max(1, fine_ray.sum()):.3f}")
 # per 8x8 tile (one wavefront): the wavefront iterates until its slowest lane is done
 def tiles(x):
     hh, ww = (H // 8) * 8, (W // 8) * 8
     return x[0, :, :hh, :ww].reshape(V, hh // 8, 8, ww // 8, 8)
 tot = tiles(far + leap + fine)
+tmax = tot.max(axis=(2, 4))
+print("per wavefront: max over lanes, percentiles over tiles " + ", ".join(f"{q}%: {np.percentile(tmax, q):.0f}" for q in qs) + f", max {tmax.max()}")
 print(f"per wavefront (8x8 tile): max over lanes of examined samples, mean over tiles {tot.max(axis=(2, 4)).mean():.2f}; "
       f"of exact evaluations {tiles(leap + fine).max(axis=(2, 4)).mean():.2f}")
