@@ -22,6 +22,10 @@ step write rocprofv3 --pmc WRITE_SIZE -d $out/write -o c --output-format csv -- 
 step sq1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $out/sq1 -o c --output-format csv -- $one
 step sq2 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU -d $out/sq2 -o c --output-format csv -- $one
 step sq3 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $out/sq3 -o c --output-format csv -- $one
-python3 tools/summarize_prof.py $out/trace $out/trace_R1 $out/fetch $out/write $out/sq1 $out/sq2 $out/sq3 > $out/summary.txt 2>&1
+oneR1="python3 tools/bench_dropin.py --shape R1 --occ same --front compiled --reps 1 --views 16"
+step fetch_R1 rocprofv3 --pmc FETCH_SIZE -d $out/fetch_R1 -o c --output-format csv -- $oneR1
+step write_R1 rocprofv3 --pmc WRITE_SIZE -d $out/write_R1 -o c --output-format csv -- $oneR1
+step sq1_R1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $out/sq1_R1 -o c --output-format csv -- $oneR1
+python3 tools/summarize_prof.py $out/trace $out/trace_R1 $out/fetch $out/write $out/sq1 $out/sq2 $out/sq3 $out/fetch_R1 $out/write_R1 $out/sq1_R1 > $out/summary.txt 2>&1
 find $out -name "*kernel_trace.csv" -size +5M -delete
 cat $out/summary.txt | grep -v "^k_stream\|^k_build\|^k_block" | head -80
