@@ -65,14 +65,14 @@
         else if (VEC_OK) hipLaunchKernelGGL((KERNEL<1, 4, 4>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<4, 1, 4>), __VA_ARGS__);                  \
     } while (0)
-// the same for k_gather, whose fourth template argument says whether the launch carries the heavy-voxel role and whose
-// fifth is the number of views whose first ID tile is fetched together (G32: 1 or 4 for fp32 rows, vp_gather.h)
-#define VP_DISPATCH_GATHER(MERGED, G32, VEC_OK, C, ...)                           \
+// the same for k_gather, whose fourth template argument is the number of views whose first ID tile is fetched together
+// (G32: 1 or 4 for fp32 rows, vp_gather.h)
+#define VP_DISPATCH_GATHER(G32, VEC_OK, C, ...)                                   \
     do {                                                                          \
-        if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather<1, 8, VP_F16_U, MERGED, GATHER_G16>), __VA_ARGS__);    \
-        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather<2, 4, 4, MERGED, G32>), __VA_ARGS__); \
-        else if (VEC_OK) hipLaunchKernelGGL((k_gather<1, 4, 4, MERGED, G32>), __VA_ARGS__);      \
-        else hipLaunchKernelGGL((k_gather<4, 1, 4, MERGED, 1>), __VA_ARGS__);               \
+        if ((VEC_OK) == 2) hipLaunchKernelGGL((k_gather<1, 8, VP_F16_U, GATHER_G16>), __VA_ARGS__);    \
+        else if ((VEC_OK) && (C) > 256) hipLaunchKernelGGL((k_gather<2, 4, 4, G32>), __VA_ARGS__); \
+        else if (VEC_OK) hipLaunchKernelGGL((k_gather<1, 4, 4, G32>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((k_gather<4, 1, 4, 1>), __VA_ARGS__);               \
     } while (0)
 
 // the one-view gather (vp_gather.h, k_gather_one).  SMALL: the view has few pixels (up to GATHER_G32_SMALL_IMAGE): a voxel gets
@@ -104,9 +104,8 @@ const char *vp_last_error(void) { return g_err; }
 
 size_t vp_workspace_bytes(int B, int V, int H, int W, int C, int dimz, int dimy, int dimx, int64_t n_rows)
 {
-    (void)C;
-    if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || n_rows <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0) return 0;
-    return make_layout(B, V, H, W, n_rows, dimz, dimy, dimx).total;
+    if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || C <= 0 || n_rows <= 0 || dimz <= 0 || dimy <= 0 || dimx <= 0) return 0;
+    return make_layout(B, V, H, W, C, n_rows, dimz, dimy, dimx).total;
 }
 
 static int workspace_status_impl(void *workspace, void *stream_, bool drain_all);
@@ -144,7 +143,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     p.dimz = dimz; p.dimy = dimy; p.dimx = dimx;
     p.B = B; p.V = V; p.C = C; p.n_rows = n_rows;
 
-    const Layout l = make_layout(B, V, H, W, n_rows, dimz, dimy, dimx, workspace_bytes);
+    const Layout l = make_layout(B, V, H, W, C, n_rows, dimz, dimy, dimx, workspace_bytes);
     if (workspace_bytes < l.total) return fail(VP_EWORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, l.total);
     if ((uintptr_t)workspace & 255) return fail(VP_EWORKSPACE, "workspace must be 256-byte aligned");
     // (every check above is host arithmetic; from here on the device is touched)
@@ -280,24 +279,48 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const long long row_hi = rec.opt_row_end < 0 ? (long long)n_rows : std::min<long long>(rec.opt_row_end, (long long)n_rows);
 
     // ---- phase 1 (on s1) ----
-    int heavy_t = 256 + 64 * B * V;   // more pixels than this in one call -> summed by a whole workgroup
+    // More pixels than heavy_t in one call -> the voxel is not one wavefront's job.  One-view calls: a workgroup of the same
+    // launch sums it (k_gather_one), threshold 256 + 64.  Every other call cuts it into parts of part_px pixels (vp_gather.h,
+    // "Split voxels"), and both numbers default to min(256 + 64*B*V, 1024): the longest item a wavefront can be handed bounds
+    // the tail of the launch -- the last items run on an emptying machine at ~4 GB/s per wavefront, 1024 rows of 2 KiB in half
+    // a millisecond.  On the close-up call of the R2T leg (60 frames staring at a wall from 0.27 m: 32 M pixels in 400 voxels,
+    // every one of them split): threshold / part 4096 / 2048 -> 11.7 ms, 2048 / 2048 -> 10.75, 1024 / 1024 -> 10.17 (0.70 / 0.76 /
+    // 0.80 of peak, one allocation, profiles/r05_ab_split_voxels.log); a call that is mostly misses, whose 2.8 ms were its
+    // longest voxel: 0.59 -> 0.79.
+    int heavy_t = (int)std::min<long long>(256 + 64ll * B * V, 1024);
+    if ((long long)B * V == 1) heavy_t = 256 + 64;
     if (rec.opt_heavy_t > 0) heavy_t = (int)std::min<long long>(rec.opt_heavy_t, 2147483647ll);   // VP_OPT_HEAVY_THRESHOLD
     if (flags & VP_FLAG_SERIAL_SUMS) heavy_t = 2147483647;
-    if (gather_only) heavy_t = st->last_heavy_t;       // the threshold the march of the previous call enlisted heavy voxels with
-#ifdef VP_DIAG
-    if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
-#endif
-    const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
     // One-view calls (the drop-in module's, the parity aggregator's) take the one-view gather: a fixed grid of wavefronts
     // dealt the size-ordered list, a wavefront's boxes computed one voxel per lane, the next voxel's tile and row fetched
     // under the current voxel's rows (vp_gather.h, k_gather_one).  VP_OPT_ONE_VIEW_GATHER = 0 keeps k_gather as the A/B arm.
     const bool one_view = (long long)B * V == 1 && rec.opt_one_view != 0;
+    // The parts' partial rows live in the buffer set's part slots, and a call's parts must never outnumber them: a split voxel
+    // has c > heavy_t >= part_px pixels and P = ceil(c / part_px) <= 2c / part_px parts, the c of a call add up to at most
+    // B*V*H*W, so part_px >= 2*B*V*H*W / slots is enough -- both values are raised to that bound (only calls larger than the
+    // bench's are: 65536 slots allow parts of 1024 pixels up to 33.5 M pixels per call).
+    int part_px = 0;
+    if (!one_view && heavy_t != 2147483647) {
+        long long ppx = rec.opt_part_px > 0 ? rec.opt_part_px : std::max<long long>(1, heavy_t);     // VP_OPT_PART_PIXELS
+        const long long px2 = 2ll * B * V * (long long)H * W;
+        ppx = std::max(ppx, (px2 + l.slot_cap - 1) / l.slot_cap);
+        part_px = (int)std::min<long long>(ppx, 2147483647ll);
+        heavy_t = std::max(heavy_t, part_px);
+    }
+    if (gather_only) { heavy_t = st->last_heavy_t; part_px = st->last_part_px; }   // the thresholds of the call whose march is reused
+#ifdef VP_DIAG
+    if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
+#endif
+    const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
+    int4 *parts = (int4 *)(ws + l.parts[q]), *split = (int4 *)(ws + l.split[q]), *pmeta = (int4 *)(ws + l.pmeta[q]);
+    float *prow = (float *)(ws + l.prow[q]);
 #define VP_LAUNCH_WORKLIST(STREAM)                                                                                              \
     hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, STREAM, (const int *)cnt_call,   \
-                       heavy_t, (long long)n_rows, work, status + ST_WORK0, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi)
+                       heavy_t, part_px, (long long)n_rows, work, status, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi, parts, split, \
+                       (int)l.slot_cap, rec.sticky_dev)
     if (gather_only) {
         // the work list of the new row range, from the histogram the previous call's march left
-        VP_HIP(hipMemsetAsync(status + ST_WORK0, 0, WORK_CLASSES * sizeof(int), s0));
+        VP_HIP(hipMemsetAsync(status + ST_WORK0, 0, ST_PLAN_WORDS * sizeof(int), s0));
         VP_LAUNCH_WORKLIST(s0);
     }
     if (!gather_only) {
@@ -311,7 +334,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         FirstHitArgs fa;
         fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
         fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
-        fa.heavy_list = heavy_list; fa.heavy_t = heavy_t; fa.status = status; fa.sticky = rec.sticky_dev;
+        fa.heavy_list = heavy_list; fa.heavy_t = (one_view || heavy_t < 0) ? heavy_t : 2147483647;      // (the march enlists heavy voxels for one-view calls only)
+        fa.status = status; fa.sticky = rec.sticky_dev;
         const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
         ProfSpan sp; sp.begin(1, s1);
         if (flags & VP_FLAG_EXACT_MARCH) {
@@ -351,14 +375,12 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     g.cnt_call = cnt_call; g.heavy_list = heavy_list; g.n_heavy = status + ST_NHEAVY;
     g.row_lo = (int)row_lo; g.row_hi = (int)row_hi;
     g.work = work; g.work_n = status + ST_WORK0;
+    g.parts = parts; g.split = split; g.pmeta = pmeta; g.prow = prow;
     g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
-    const int blocks_n = (int)((n_rows - 1 + 3) / 4);
-    // Heavy voxels: the first workgroups of the gather's own launch when the call has many views; a launch of their own
-    // in front of it, 16 wavefronts per voxel, when it has few (vp_gather.h)
-    const bool merged_heavy = (long long)B * V >= 8;
-    const bool small_image = merged_heavy && (long long)H * W <= GATHER_G32_SMALL_IMAGE;   // grouping needs views to group
-    g.heavy_blocks = merged_heavy ? HEAVY_BLOCKS : 0;
+    // grouped ID-tile fetch on small images needs views to group
+    const bool small_image = (long long)B * V >= 8 && (long long)H * W <= GATHER_G32_SMALL_IMAGE;
+    g.heavy_blocks = 0;
     if (pipe && !gather_only) VP_HIP(hipStreamWaitEvent(s0, ps->fh_done[q], 0));
     if (one_view) {
         // a fixed number of workgroups per CU.  The kernel's registers admit 4 at a time; 16 are launched, so that the
@@ -375,21 +397,24 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         g.heavy_blocks = heavy_t != 2147483647 ? (int)std::min<unsigned>(HEAVY_BLOCKS, nblk) : 0;
         if (n_rows > 1) VP_DISPATCH_GATHER_ONE((long long)H * W <= GATHER_G32_SMALL_IMAGE, vec_ok, C, dim3(nblk), dim3(256), 0, s0, g, p);
         sp.end();
-    }
-    // (with VP_FLAG_SERIAL_SUMS no voxel can be heavy: the launch -- 5 us of a 0.1-ms one-view call -- is left out)
-    if (!one_view && !merged_heavy && heavy_t != 2147483647) {
-        ProfSpan sp; sp.begin(3, s0);
-        VP_DISPATCH_KVU(k_gather_heavy, vec_ok, C, dim3(HEAVY_BLOCKS), dim3(GW_ALONE * 64), 0, s0, g, p);
-        sp.end();
-    }
-    if (!one_view) {
-        ProfSpan sp; sp.begin(2, s0);
-        const dim3 ggrid(g.heavy_blocks + (blocks_n > 0 ? blocks_n : 0));
-        if (ggrid.x == 0) { /* n_rows == 1: only the dummy row 0, nothing to gather */ }
-        else if (merged_heavy && small_image) VP_DISPATCH_GATHER(true, 4, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
-        else if (merged_heavy) VP_DISPATCH_GATHER(true, 1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
-        else VP_DISPATCH_GATHER(false, 1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
-        sp.end();
+    } else if (n_rows > 1) {
+        // one wavefront per item of the work list: at most one item per voxel row that is not split, plus the parts
+        const long long items = (n_rows - 1) + (part_px > 0 ? l.slot_cap : 0);
+        {
+            ProfSpan sp; sp.begin(2, s0);
+            const dim3 ggrid((unsigned)((items + 3) / 4));
+            if (small_image) VP_DISPATCH_GATHER(4, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+            else VP_DISPATCH_GATHER(1, vec_ok, C, ggrid, dim3(256), 0, s0, g, p);
+            sp.end();
+        }
+        if (part_px > 0) {
+            // the split voxels' partial rows -> their rows in `out`, in slot order (with VP_FLAG_SERIAL_SUMS nothing is split:
+            // the launch is left out)
+            ProfSpan sp; sp.begin(3, s0);
+            const dim3 cgrid((unsigned)std::min<long long>(COMBINE_BLOCKS, std::max<long long>(1, l.slot_cap / 2)));
+            VP_DISPATCH_KVU(k_combine_parts, vec_ok, C, cgrid, dim3(256), 0, s0, g, p);
+            sp.end();
+        }
     }
     if (pipe) {
         // (a gather-only call re-records the event of the set it shares with its predecessor and does not advance the sets)
@@ -403,7 +428,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     VP_HIP(hipGetLastError());
     st->last_B = B; st->last_V = V; st->last_H = H; st->last_W = W; st->last_C = C; st->last_q = q;
     st->last_f16 = feats_f16; st->last_feats = (const void *)feats; st->last_out = (const void *)out; st->last_count = (const void *)count;
-    st->last_vmi = (const void *)vmi; st->last_ranged = ranged; st->last_heavy_t = heavy_t;
+    st->last_vmi = (const void *)vmi; st->last_ranged = ranged; st->last_heavy_t = heavy_t; st->last_part_px = part_px;
     st->has_hit = true; st->hit_off = l.hit[q];
     hit_guard.keep = true;
     if (flags & VP_FLAG_SYNC) return workspace_status_impl(workspace, stream_, true);
@@ -736,6 +761,7 @@ int vp_workspace_set_option(void *workspace, int option, long long value)
     case VP_OPT_ROW_BEGIN:       rec->opt_row_begin = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ROW_END:         rec->opt_row_end = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ONE_VIEW_GATHER: rec->opt_one_view = value >= 0 ? value : -1; return VP_OK;
+    case VP_OPT_PART_PIXELS:     rec->opt_part_px = value > 0 ? value : -1; return VP_OK;
     default: return fail(VP_EINVAL, "unknown workspace option %d", option);
     }
 }

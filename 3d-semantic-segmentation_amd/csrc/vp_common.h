@@ -106,10 +106,11 @@ struct WsState {
     long long opt_march_lds_kb = -1;
     long long opt_row_begin = -1, opt_row_end = -1;     // VP_OPT_ROW_BEGIN / _END: phase 2 gathers IDs in [begin, end)
     long long opt_one_view = -1;                        // VP_OPT_ONE_VIEW_GATHER: 0 = one-view calls through k_gather (A/B arm)
+    long long opt_part_px = -1;                         // VP_OPT_PART_PIXELS: pixels per part of a split voxel (-1: default)
     // arguments of the last vp_project_features call (VP_FLAG_GATHER_ONLY repeats its phase 2 on another row range)
     int last_B = 0, last_V = 0, last_H = 0, last_W = 0, last_C = 0, last_q = 0;
     bool last_f16 = false, last_ranged = false;
-    int last_heavy_t = 0;
+    int last_heavy_t = 0, last_part_px = 0;
     const void *last_feats = nullptr, *last_out = nullptr, *last_count = nullptr, *last_vmi = nullptr;
     // first-hit image of the last call (vp_copy_hit_image)
     bool has_hit = false;
@@ -231,7 +232,10 @@ struct Params {
 // ST_HDR_*: the workspace header (set 0 only): magic, the generation of the record that initialised this memory, the key
 // of the tables it holds (0 while none are sealed) -- written by k_ws_open / k_ws_seal, compared by every call's k_zero_call.
 enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_ZERO = 3 /* never written */, ST_STUCK = 4, ST_OCCDIFF = 5, ST_STALE = 6,
+       ST_HEAVY_T = 7,                         // per-call: the heavy threshold in force (after the part-slot bound), for the counters
        ST_WORK0 = 16, WORK_CLASSES = 8,        // per-call: number of voxels in each size class of the gather's work list
+       ST_NPARTS = 24, ST_NSPLIT = 25,         // per-call, next to the class counts: parts and split voxels planned by k_worklist
+       ST_PLAN_WORDS = WORK_CLASSES + 2,       // ST_WORK0 .. ST_NSPLIT: what a work-list run (re)counts
        ST_CALL_WORDS = 32,
        ST_HDR_MAGIC = 56, ST_HDR_GEN = 57, ST_HDR_TABLES = 58,
        ST_STICKY_STALE = 61, ST_STICKY_BADID = 62, ST_STICKY_STUCK = 63, ST_WORDS = 64 };
@@ -277,6 +281,8 @@ struct Layout {
     size_t cell_of_id, mask64, near2, dist, dist_tmp;    // occupancy-derived tables (shared)
     size_t occ_copy;                                     // (int)occupancy the tables were built from (VP_FLAG_VERIFY_ACCEL)
     size_t status[2], cnt_call[2], heavy[2], work[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
+    size_t parts[2], split[2], pmeta[2], prow[2];        // split voxels (vp_gather.h): part items, split list, per-part results
+    long long slot_cap;                                  // part slots per set
     size_t total;
     int nbx, nby, nbz;
     long long nblk;   // occupancy blocks (4x4x4 cells) per batch
@@ -287,7 +293,22 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 // `capacity` = bytes of the caller's workspace (0 = compute the minimum).  The two per-call buffer sets sit
 // at offsets that depend only on (B, n_rows, grid dims, capacity), never on V/H/W, so that consecutive
 // pipelined calls of different V on one workspace cannot alias each other's buffers.
-Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int dimy, int dimx, size_t capacity = 0)
+// Part slots of one buffer set (split voxels, vp_gather.h): a voxel above the heavy threshold is summed as P parts, each
+// part's C-wide partial row in a slot.  The number of slots bounds how finely a call can be cut: with part_px >= 2*B*V*H*W /
+// slots and heavy_t >= part_px the parts of a call can never outnumber the slots (project_impl raises both to that bound).
+// 65536 slots -- parts of 1024 pixels for calls of up to 33 M pixels (60 views of 968x548) --, fewer when the rows are wide
+// (128 MiB of partial rows per set at most) or the call is small.
+#ifndef VP_MAX_SLOTS
+#define VP_MAX_SLOTS 65536
+#endif
+inline long long part_slot_cap(int B, int V, int H, int W, int C)
+{
+    const long long px2 = 2ll * B * V * (long long)H * W;
+    const long long by_bytes = std::max<long long>(1024, ((long long)VP_MAX_SLOTS * 2048) / (std::max(C, 1) * 4ll));
+    return std::max<long long>(64, std::min<long long>(VP_MAX_SLOTS, std::min(px2, by_bytes)));
+}
+
+Layout make_layout(int B, int V, int H, int W, int C, long long n_rows, int dimz, int dimy, int dimx, size_t capacity = 0)
 {
     Layout l;
     size_t off = 0;
@@ -307,12 +328,19 @@ Layout make_layout(int B, int V, int H, int W, long long n_rows, int dimz, int d
         l.heavy[q] = off;    off += align256(size_t(n_rows) * sizeof(int));
         l.work[q] = off;     off += align256(size_t(WORK_CLASSES) * size_t(n_rows) * sizeof(int));
     }
-    const size_t per_set = align256(size_t(B) * V * sizeof(ViewEntry)) + align256(size_t(B) * V * H * W * sizeof(int));
+    l.slot_cap = part_slot_cap(B, V, H, W, C);
+    const size_t sz_view = align256(size_t(B) * V * sizeof(ViewEntry)), sz_hit = align256(size_t(B) * V * H * W * sizeof(int));
+    const size_t sz_i4 = align256(size_t(l.slot_cap) * 16), sz_prow = align256(size_t(l.slot_cap) * size_t(C) * sizeof(float));
+    const size_t per_set = sz_view + sz_hit + 3 * sz_i4 + sz_prow;
     size_t half = per_set;
     if (capacity > off + 2 * per_set) half = ((capacity - off) / 2) & ~size_t(255);
     for (int q = 0; q < 2; q++) {
         l.viewtab[q] = off + q * half;
-        l.hit[q] = l.viewtab[q] + align256(size_t(B) * V * sizeof(ViewEntry));
+        l.hit[q] = l.viewtab[q] + sz_view;
+        l.parts[q] = l.hit[q] + sz_hit;
+        l.split[q] = l.parts[q] + sz_i4;
+        l.pmeta[q] = l.split[q] + sz_i4;
+        l.prow[q] = l.pmeta[q] + sz_i4;
     }
     l.total = off + 2 * per_set;
     return l;

@@ -1,5 +1,8 @@
 // vp_gather.h -- phase 2: one wavefront per voxel gathers and sums the feature rows of the pixels that first-hit it
-// (k_gather); the voxels with very many pixels are shared by the four wavefronts of the launch's first workgroups.
+// (k_gather).  A voxel that collected more pixels than the heavy threshold in the call is cut into PARTS (round 5): each
+// part is an item of the same work list, summed by one wavefront into a partial row, and a small follow-up kernel
+// (k_combine_parts) adds the partial rows to the voxel's row in a fixed order.  One-view calls have a kernel of their
+// own (k_gather_one), whose first workgroups share the view's heavy voxels four wavefronts apiece.
 // Included by voxproj.hip only.
 #pragma once
 
@@ -216,22 +219,26 @@ struct GatherArgs {
     const float *intr;
     const int *cell_of_id;
     const int *cnt_call;
-    const int *heavy_list;   // IDs whose per-call pixel count exceeds heavy_t (appended by phase 1)
+    const int *heavy_list;   // one-view calls: IDs whose pixel count exceeds heavy_t (appended by phase 1)
     const int *n_heavy;
     int heavy_t;
     int row_lo, row_hi;      // phase 2 of this launch covers the voxel IDs in [row_lo, row_hi) (VP_OPT_ROW_BEGIN / _END)
-    int heavy_blocks;        // leading workgroups of k_gather that take the heavy voxels (0: k_gather_heavy does)
+    int heavy_blocks;        // k_gather_one: leading workgroups that take the view's heavy voxels
     const int *work;         // work list of this call: WORK_CLASSES arrays of n_rows voxel IDs, by size class (k_worklist)
-    const int *work_n;       // voxels per class
+    const int *work_n;       // voxels per class; [WORK_CLASSES] = parts planned, [WORK_CLASSES + 1] = split voxels (ST_NPARTS, ST_NSPLIT)
+    const int4 *parts;       // part items of the split voxels: {id, part, P, first slot of the voxel}; the item's index is its slot
+    const int4 *split;       // split voxels: {id, first slot, P, pixels in the call}
+    int4 *pmeta;             // per slot: {pixels found, views that contributed, first such view, last such view}
+    float *prow;             // per slot: the part's C-wide partial row
     int *count;
     int *views_hit;          // nullable: += number of views of this call in which the voxel got >= 1 pixel
     float *out;
     int *status;
 };
 
-constexpr int GW_MERGED = 4;     // wavefronts that share one heavy voxel inside k_gather (= one of its workgroups)
-constexpr int GW_ALONE = 16;     // ... in k_gather_heavy, the separate launch used for calls of few views
-constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather that take the heavy voxels
+constexpr int GW_MERGED = 4;     // wavefronts that share one heavy voxel inside k_gather_one (= one of its workgroups)
+constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather_one that take the view's heavy voxels
+constexpr int COMBINE_BLOCKS = 512; // grid of k_combine_parts (a workgroup per split voxel at a time)
 
 // Views whose first ID tile is fetched together by the one-wavefront gather (template argument G of k_gather; 1 = one view
 // at a time).  fp16 rows: 4 (-1 % pipelined, round 2).  fp32 rows: 4 for small images (a voxel of R1's 484x274 views gathers
@@ -460,7 +467,114 @@ __device__ __forceinline__ void gather_voxel_wave(const GatherArgs &g, const Par
     }
 }
 
-// Heavy role (the first HEAVY_BLOCKS workgroups of k_gather): the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
+// ------------------------------------------------------------------------------------------------
+// Split voxels (round 5).  A voxel that collected more than heavy_t pixels in the call -- a surface patch a hand-held camera
+// stares at from 0.3 m for sixty consecutive frames collects 10^5 and more -- is not one wavefront's job: at the ~5 GB/s one
+// wavefront pulls, 200 MB of rows last longer than the whole launch.  Rounds 1-4 gave such a voxel to ONE workgroup of the
+// launch's first 128 (four wavefronts splitting each view's box rows, combined through LDS view by view): enough for the
+// benign room (76 voxels of <= 8.8 k pixels per pass), 0.25-0.27 of peak on a trajectory whose close-ups put 70-100 % of a
+// call's pixels into such voxels (profiles/r05_before_*.log).  Now:
+//   * k_worklist PLANS: a voxel with c > heavy_t pixels becomes P = ceil(c / part_px) parts; each part is an item
+//     {id, part, P} in its own slot, and the parts lead the work list (they are the longest items);
+//   * a PART is a contiguous piece of the voxel's pixel sequence in (b, v, y, x) order, cut by search-box AREA: with
+//     A = the summed area of the voxel's pixel boxes over all views of the call, part k owns the box rows whose first
+//     pixel's running area index lies in [A k / P, A (k+1) / P) -- every row of every view belongs to exactly one part,
+//     whatever the boxes are.  One wavefront sums its rows in order from zero into a partial row (gather_part_wave);
+//   * k_combine_parts (one workgroup per split voxel, after the gather on the same stream) adds the partial rows to the
+//     row in `out` in slot order -- a fixed tree, so results are reproducible run to run and independent of which
+//     wavefront ran when; they differ from the serial order in the last bits only (inside the 1e-4 bar, tested per
+//     element); pixel counts add exactly; a view shared by two neighbouring parts is counted once.  If the parts found
+//     fewer pixels than the march counted (the boxes are only hints), the voxel is redone over whole images.
+// No float atomics, no inter-workgroup hand-off inside a launch (the partial rows cross a kernel boundary).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_sum_nonneg(int v)
+{
+    long long s = 0;
+    unsigned long long m = __ballot(v != 0);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        s += __builtin_amdgcn_readlane(v, l);
+    }
+    return s;
+}
+
+template <int K, int VEC, int U>
+__device__ __forceinline__ void gather_part_wave(const GatherArgs &g, const Params &p, int slot, int lane)
+{
+    const int4 it = g.parts[slot];
+    const int id = it.x, part = it.y, P = it.z;
+    const int W = p.width, H = p.height, C = p.C;
+    const long long HW = (long long)H * W;
+    const float hh = box_half_edge(p);
+    const float zn = near_plane(p);
+    constexpr int CB = 64 * K * VEC;
+#ifdef VP_PART_JITTER
+    // experiment: parts start up to ~200 us apart (do the parts of a close-up call, all of one size, march through memory in step?)
+    for (int i = 0, n = (int)((unsigned)(slot * 2654435761u) >> 27); i < n * 2; i++) __builtin_amdgcn_s_sleep(127);
+#endif
+    // pass 1: the voxel's total box area over the call's views
+    long long A = 0;
+    for (int b = 0; b < p.B; b++) {
+        float cxw, cyw, czw;
+        if (!voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
+        const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
+        for (int vbase = 0; vbase < p.V; vbase += 64) {
+            const int v = vbase + lane;
+            int x0 = 0, y0 = 0, x1 = -1, y1 = -1, area = 0;
+            if (v < p.V && voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1))
+                area = (x1 - x0 + 1) * (y1 - y0 + 1);
+            A += wave_sum_nonneg(area);
+        }
+    }
+    const long long lo = A * part / P, hi = A * (part + 1) / P;      // A < 2^47, P <= 2^15
+    int found0 = 0, nviews = 0, first_v = -1, last_v = -1;
+    for (int cb = 0; cb < C; cb += CB) {
+        Acc<K, VEC> acc;
+#pragma unroll
+        for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
+        int found = 0;
+        long long a0 = 0;      // area of the boxes in front of the current view
+        for (int b = 0; b < p.B && a0 < hi; b++) {
+            float cxw, cyw, czw;
+            if (!voxel_centre(g, p, b, id, cxw, cyw, czw)) continue;
+            const float fx = g.intr[b * 4 + 0], fy = g.intr[b * 4 + 1], mx = g.intr[b * 4 + 2], my = g.intr[b * 4 + 3];
+            for (int vbase = 0; vbase < p.V && a0 < hi; vbase += 64) {
+                const int v = vbase + lane;
+                int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+                bool ne = false;
+                if (v < p.V) ne = voxel_box(g.viewtab[b * p.V + v], fx, fy, mx, my, cxw, cyw, czw, hh, zn, W, H, x0, y0, x1, y1);
+                unsigned long long vm = __ballot(ne);
+                while (vm && a0 < hi) {
+                    const int l = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                    const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
+                    const long long bw = bx1 - bx0 + 1, av = bw * (by1 - by0 + 1);
+                    // rows r of this box with lo <= a0 + r*bw < hi
+                    const long long r_lo = lo > a0 ? (lo - a0 + bw - 1) / bw : 0;
+                    const long long r_hi = hi < a0 + av ? (hi - a0 + bw - 1) / bw : (long long)(by1 - by0 + 1);
+                    a0 += av;
+                    if (r_lo >= r_hi) continue;
+                    const long long bv = (long long)b * p.V + vbase + l;
+                    const int before = found;
+                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0 + (int)r_lo, bx1,
+                                        by0 + (int)r_hi - 1, cb, lane, acc, found);
+                    if (cb == 0 && found > before) {
+                        nviews++;
+                        if (first_v < 0) first_v = (int)bv;
+                        last_v = (int)bv;
+                    }
+                }
+            }
+        }
+        acc_store<K, VEC, false>(acc, g.prow + (long long)slot * C + cb, cb, C, lane);
+        if (cb == 0) found0 = found;
+    }
+    if (lane == 0) g.pmeta[slot] = make_int4(found0, nviews, first_v, last_v);
+}
+
+// Heavy role (the first HEAVY_BLOCKS workgroups of k_gather_one): the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
 // in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
 // each wavefront sums its range in raster order, and the partial rows are combined through LDS in
 // wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
@@ -569,10 +683,16 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
 constexpr int WL_PER_THREAD = 16;   // IDs per lane of k_worklist: a 256-thread workgroup bins 4096 voxel IDs
 
 // [row_lo, row_hi): the IDs this call's phase 2 gathers (VP_OPT_ROW_BEGIN / _END; [1, n_rows) when no range is set).
-__global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, long long n_rows,
-                                                  int *__restrict__ work, int *work_n, int wl_blocks,
+// part_px > 0: the launch also PLANS the split voxels (see "Split voxels" above): a voxel with more than heavy_t pixels
+// gets P = ceil(c / part_px) consecutive part slots and an entry in the split list; slots and entries are handed out per
+// workgroup (LDS counters, two global atomics per workgroup).  The host chose part_px and heavy_t such that the parts of a
+// call cannot outnumber slot_cap (project_impl); the guard below only keeps a broken promise from writing out of bounds.
+// part_px == 0 (one-view calls): the voxels above heavy_t are in the march's heavy list and stay out of this list.
+__global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, int part_px, long long n_rows,
+                                                  int *__restrict__ work, int *status, int wl_blocks,
                                                   const float *__restrict__ vmi, ViewEntry *viewtab, int n_views,
-                                                  long long row_lo, long long row_hi)
+                                                  long long row_lo, long long row_hi, int4 *__restrict__ parts,
+                                                  int4 *__restrict__ split, int slot_cap, int *sticky)
 {
     if ((int)blockIdx.x >= wl_blocks) {
         // trailing workgroups: the call's view table (phase 2's world->camera maps), one thread per view -- riding on
@@ -581,10 +701,14 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
         if (v < n_views) view_entry(vmi, viewtab, v);
         return;
     }
+    int *work_n = status + ST_WORK0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_HEAVY_T] = heavy_t;
     // Appends are aggregated per WORKGROUP through LDS: a handful of global atomics per 4096 IDs.  (Returning integer
     // atomics on a few hot addresses are exactly what slows a concurrently running gather -- DESIGN.md section 2.)
-    __shared__ int n_cls[WORK_CLASSES], base_cls[WORK_CLASSES];
-    if (threadIdx.x < WORK_CLASSES) n_cls[threadIdx.x] = 0;
+    // Counters WORK_CLASSES and WORK_CLASSES + 1: part slots and split voxels.
+    __shared__ int n_cls[WORK_CLASSES + 2], base_cls[WORK_CLASSES + 2], n_split2;
+    if (threadIdx.x < WORK_CLASSES + 2) n_cls[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_split2 = 0;
     __syncthreads();
     const long long id0 = (long long)blockIdx.x * (256 * WL_PER_THREAD);
     int cls[WL_PER_THREAD], rank[WL_PER_THREAD];
@@ -594,57 +718,67 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
         const long long id = id0 + (long long)j * 256 + threadIdx.x;
         int c = 0;
         if (id >= row_lo && id < row_hi) c = cnt_call[id];
-        cls[j] = (c > 0 && c <= heavy_t) ? min(WORK_CLASSES - 1, max(0, 28 - __builtin_clz(c))) : -1;     // floor(log2 c) - 3
-        rank[j] = cls[j] >= 0 ? atomicAdd(&n_cls[cls[j]], 1) : 0;
+        cls[j] = -1;
+        rank[j] = 0;
+        if (c > 0 && c <= heavy_t) {
+            cls[j] = min(WORK_CLASSES - 1, max(0, 28 - __builtin_clz(c)));     // floor(log2 c) - 3
+            rank[j] = atomicAdd(&n_cls[cls[j]], 1);
+        } else if (c > heavy_t && part_px > 0) {
+            cls[j] = WORK_CLASSES;
+            rank[j] = atomicAdd(&n_cls[WORK_CLASSES], (c + part_px - 1) / part_px);
+            atomicAdd(&n_cls[WORK_CLASSES + 1], 1);
+        }
     }
     __syncthreads();
-    if (threadIdx.x < WORK_CLASSES) {
+    if (threadIdx.x < WORK_CLASSES + 2) {
         const int n = n_cls[threadIdx.x];
         base_cls[threadIdx.x] = n > 0 ? atomicAdd(&work_n[threadIdx.x], n) : 0;
+        if (threadIdx.x == WORK_CLASSES + 1 && n > 0) atomicAdd(&status[ST_NHEAVY], n);      // the counter tests and the bench read
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < WL_PER_THREAD; j++)
-        if (cls[j] >= 0)
-            work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = (int)(id0 + (long long)j * 256 + threadIdx.x);
+    for (int j = 0; j < WL_PER_THREAD; j++) {
+        const int id = (int)(id0 + (long long)j * 256 + threadIdx.x);
+        if (cls[j] >= 0 && cls[j] < WORK_CLASSES) {
+            work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = id;
+        } else if (cls[j] == WORK_CLASSES) {
+            const int c = cnt_call[id];
+            const int P = (c + part_px - 1) / part_px;
+            const int base = base_cls[WORK_CLASSES] + rank[j];
+            const int sidx = base_cls[WORK_CLASSES + 1] + atomicAdd(&n_split2, 1);
+            if (base + P > slot_cap || sidx >= slot_cap) {      // cannot happen (see above); loud rather than out of bounds
+                atomicOr(&status[ST_BADID], 1);
+                *(volatile int *)&sticky[ST_STICKY_BADID] = 1;
+                continue;
+            }
+            split[sidx] = make_int4(id, base, P, c);
+            for (int q = 0; q < P; q++) parts[base + q] = make_int4(id, q, P, base);
+        }
+    }
 }
 
-// MERGED = true: the launch's first g.heavy_blocks workgroups take the heavy voxels (calls of 8 or more views); 101-106 VGPRs
-// (97 before round 3's write-through row stores and grouped tile fetch; allocated 104-112 either way), i.e. 4 wavefronts per SIMD -- in pipelined mode a gain, because a fifth gather wave would take the room the next call's
-// march needs (forcing <= 96 registers with __launch_bounds__(256, 5), one allocation: pipelined +2.5 % fp16 / +2 % R1 /
-// -0.4 % fp32; serial phases -1.0 .. -1.4 %).
-// MERGED = false: without that role the kernel needs 96 VGPRs = 5 wavefronts per SIMD, worth 5 % on a one-view call
-// (0.372 vs 0.392 ms per blocking R2 call); the heavy voxels of such calls go to k_gather_heavy below.
-template <int K, int VEC, int U, bool MERGED, int G>
+// The gather of every call with more than one view.  Wavefront w of the grid takes item w of the call's work list: first
+// the parts of the split voxels (the longest items), then the voxels of the size classes from the largest class down --
+// long items start first, short ones fill the tail.  104-112 VGPRs allocated = 4 wavefronts per SIMD -- in pipelined mode a
+// gain, because a fifth gather wave would take the room the next call's march needs (forcing <= 96 registers with
+// __launch_bounds__(256, 5), one allocation: pipelined +2.5 % fp16 / +2 % R1 / -0.4 % fp32; serial phases -1.0 .. -1.4 %).
+// The grid is sized for every row plus every part slot (the host does not know how many a call uses): the wavefronts
+// beyond the end of the list read the ten counters and exit.
+template <int K, int VEC, int U, int G>
 __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
 {
     // The gather is HBM-bound: what matters is that its few instructions (address arithmetic, load issue) go out
     // the moment data returns.  Raised wave priority lets it win instruction arbitration against the issue-bound
     // march waves of the next call that share the SIMD in pipelined mode.
     __builtin_amdgcn_s_setprio(3);
-    __shared__ __attribute__((aligned(16))) float part[MERGED ? GW_MERGED : 1][MERGED ? 64 * K * VEC : 1];
-    __shared__ int part_found[GW_MERGED];
-    if (MERGED && (int)blockIdx.x < g.heavy_blocks) {
-        // Heavy role: the first workgroups of the grid -- so they start before anything else, the longest jobs first --
-        // take the voxels that collected more than heavy_t pixels in this call, one voxel per workgroup at a time, the
-        // four wavefronts splitting each view's box rows (gather_voxel_block).  First the search boxes; on a pixel-count
-        // mismatch nothing was stored: redo over whole images.
-        const int n_heavy = *g.n_heavy;
-        for (int h = blockIdx.x; h < n_heavy; h += g.heavy_blocks) {
-            const int id = g.heavy_list[h];
-            if (id < g.row_lo || id >= g.row_hi) continue;     // the list is the whole call's; the other range's gather takes it
-            const int expected = g.cnt_call[id];
-            if constexpr (MERGED) {
-                if (!gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, false)) {
-                    if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-                    gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, true);
-                }
-            }
-        }
+    const int lane = threadIdx.x & 63;
+    long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_parts = g.work_n[WORK_CLASSES];
+    if (w < n_parts) {
+        gather_part_wave<K, VEC, U>(g, p, (int)w, lane);
         return;
     }
-    const int lane = threadIdx.x & 63;
-    long long w = (long long)((int)blockIdx.x - (MERGED ? g.heavy_blocks : 0)) * 4 + (threadIdx.x >> 6);
+    w -= n_parts;
     int id = 0;
 #pragma unroll
     for (int k = WORK_CLASSES - 1; k >= 0; k--) {
@@ -654,25 +788,110 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     }
     if (id == 0) return;
     const int expected = g.cnt_call[id];
-    gather_voxel_wave<K, VEC, U, G, MERGED>(g, p, id, expected, lane);
+    gather_voxel_wave<K, VEC, U, G, true>(g, p, id, expected, lane);
 }
 
-// Calls of few views (the drop-in module's one view per call): the heavy voxels are few, each a large share of a short
-// launch: a launch of their own with 16 wavefronts per voxel, in front of k_gather<..., false> on the same stream.  (With 16
-// or 32 views per call the merged form above is 2-4 % faster per call.)
+// After k_gather on the same stream: one workgroup per split voxel at a time adds the voxel's partial rows to its row in
+// `out`, in slot order.  The four wavefronts take four consecutive runs of the P slots (U rows in flight each), their
+// sums meet in LDS and are added to the old row in wavefront order: a fixed tree for a given P.  Pixel counts add exactly;
+// a view that two neighbouring parts share is counted once (parts cover ascending, contiguous stretches of the view
+// sequence, so only the boundary views can repeat).  Parts that found fewer pixels than the march counted: the search
+// boxes missed some (an ID labelling several cells, a degenerate pose) -- the voxel is redone over whole images.
 template <int K, int VEC, int U>
-__global__ __launch_bounds__(GW_ALONE * 64) void k_gather_heavy(GatherArgs g, Params p)
+__global__ __launch_bounds__(256) void k_combine_parts(GatherArgs g, Params p)
 {
-    __shared__ __attribute__((aligned(16))) float part[GW_ALONE][64 * K * VEC];
-    __shared__ int part_found[GW_ALONE];
-    const int n_heavy = *g.n_heavy;
-    for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const int id = g.heavy_list[h];
-        if (id < g.row_lo || id >= g.row_hi) continue;
-        const int expected = g.cnt_call[id];
-        if (!gather_voxel_block<K, VEC, U, GW_ALONE>(g, p, id, expected, part, part_found, false)) {
-            if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-            gather_voxel_block<K, VEC, U, GW_ALONE>(g, p, id, expected, part, part_found, true);
+    __shared__ __attribute__((aligned(16))) float part[GW_MERGED][64 * K * VEC];
+    __shared__ int part_found[GW_MERGED];
+    __shared__ int meta[GW_MERGED][4];
+    const int n_split = g.work_n[WORK_CLASSES + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
+    const int C = p.C;
+    constexpr int CB = 64 * K * VEC;
+    constexpr int R = (CB + GW_MERGED * 64 - 1) / (GW_MERGED * 64);
+    for (int j = blockIdx.x; j < n_split; j += gridDim.x) {
+        const int4 sp = g.split[j];
+        const int id = sp.x, base = sp.y, P = sp.z, expected = sp.w;
+        const int q0 = (int)((long long)P * w / GW_MERGED), q1 = (int)((long long)P * (w + 1) / GW_MERGED);
+        {   // this wavefront's run of slots: pixels found, distinct views, first and last contributing view
+            int f = 0, nv = 0, first = -1, last = -1;
+            for (int q = q0; q < q1; q++) {
+                const int4 m = g.pmeta[base + q];
+                f += m.x;
+                if (m.y > 0) {
+                    nv += m.y - (m.z == last ? 1 : 0);
+                    if (first < 0) first = m.z;
+                    last = m.w;
+                }
+            }
+            if (lane == 0) { meta[w][0] = f; meta[w][1] = nv; meta[w][2] = first; meta[w][3] = last; }
+        }
+        __syncthreads();
+        int found = 0, nviews = 0;
+        {
+            int last = -1;
+#pragma unroll
+            for (int ww = 0; ww < GW_MERGED; ww++) {
+                found += meta[ww][0];
+                if (meta[ww][1] > 0) {
+                    nviews += meta[ww][1] - (meta[ww][2] == last ? 1 : 0);
+                    last = meta[ww][3];
+                }
+            }
+        }
+        __syncthreads();
+        if (found != expected) {
+            if (tid == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
+            gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, true);      // count / views_hit included
+            __syncthreads();
+            continue;
+        }
+        for (int cb = 0; cb < C; cb += CB) {
+            Acc<K, VEC> acc;
+#pragma unroll
+            for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
+            for (int q = q0; q < q1; q += U) {
+                Acc<K, VEC> r[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (q + u < q1) acc_load<K, VEC>(r[u], g.prow + (long long)(base + q + u) * C + cb, cb, C, lane);
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (q + u < q1) {
+#pragma unroll
+                        for (int i = 0; i < K * VEC; i++) acc.a[i] += r[u].a[i];
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if constexpr (VEC == 8) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+                        *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 8 + h * 4]) =
+                            make_float4(acc.a[k * 8 + h * 4 + 0], acc.a[k * 8 + h * 4 + 1], acc.a[k * 8 + h * 4 + 2], acc.a[k * 8 + h * 4 + 3]);
+                } else if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4 *>(&part[w][(k * 64 + lane) * 4]) =
+                        make_float4(acc.a[k * 4 + 0], acc.a[k * 4 + 1], acc.a[k * 4 + 2], acc.a[k * 4 + 3]);
+                } else {
+                    part[w][k * 64 + lane] = acc.a[k];
+                }
+            }
+            __syncthreads();
+            float *orow = g.out + (long long)id * C + cb;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int c = tid + r * GW_MERGED * 64;
+                if (c < CB && cb + c < C) {
+                    float run = orow[c];
+#pragma unroll
+                    for (int ww = 0; ww < GW_MERGED; ww++) run += part[ww][c];
+                    orow[c] = run;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            g.count[id] += found;
+            if (g.views_hit) g.views_hit[id] += nviews;
         }
     }
 }

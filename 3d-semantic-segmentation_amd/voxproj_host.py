@@ -58,6 +58,7 @@ VP_OPT_MARCH_LDS_KB = 2
 VP_OPT_ROW_BEGIN = 3
 VP_OPT_ROW_END = 4
 VP_OPT_ONE_VIEW_GATHER = 5
+VP_OPT_PART_PIXELS = 6
 
 
 class VoxprojError(RuntimeError):
@@ -209,7 +210,8 @@ class Workspace:
         state = (_options_version, tuple(sorted(self.options.items())))
         if self.buf is None or self._applied == state:
             return
-        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1, VP_OPT_ROW_BEGIN: -1, VP_OPT_ROW_END: -1, VP_OPT_ONE_VIEW_GATHER: -1}
+        merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1, VP_OPT_ROW_BEGIN: -1, VP_OPT_ROW_END: -1, VP_OPT_ONE_VIEW_GATHER: -1,
+                  VP_OPT_PART_PIXELS: -1}
         merged.update(_default_options)
         merged.update(self.options)
         for opt, val in merged.items():
@@ -378,13 +380,15 @@ def hit_image(ws, device):
 
 
 def counters(ws, device):
-    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss, n_heavy)."""
+    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss, n_heavy, heavy_t, n_parts) -- n_heavy = voxels
+    above the heavy threshold in force (heavy_t: the option or min(256 + 64*B*V, 1024), raised to the part-slot bound where that binds),
+    n_parts = the parts they were cut into (0 for one-view calls, whose heavy voxels a workgroup sums)."""
     import torch
-    arr = (ctypes.c_int32 * 8)()
+    arr = (ctypes.c_int32 * 32)()
     ptr = ws.ptr()
     stream = torch.cuda.current_stream(device).cuda_stream
-    check(lib().vp_workspace_counters(ptr, arr, 8, stream))
-    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]), n_heavy=int(arr[2]))
+    check(lib().vp_workspace_counters(ptr, arr, 32, stream))
+    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]), n_heavy=int(arr[2]), heavy_t=int(arr[7]), n_parts=int(arr[24]))
 
 
 def table_builds(ws):

@@ -48,7 +48,25 @@ WORKLOADS = {
     "R2": (200000, 300, 968, 548, 512),      # BASELINE config 3 (metric config)
     "R1": (80000, 100, 484, 274, 512),       # BASELINE config 2
     "S0": (10000, 8, 64, 64, 32),            # BASELINE config 1 (plumbing)
+    # round 5: away from the benign room
+    "A1": (87319, 216, 876, 584, 512),       # the problem size the reference's authors ran (AGG:18,28,106,209; cell 0.04 m, DSLR
+                                             # intrinsics of camera_params/colmap_camera_params.sh:7-14 at 0.5x) on a hand-held trajectory
+    "R2T": (200000, 300, 968, 548, 512),     # the metric config's shape on a hand-held trajectory (close-ups, missing wall, clutter 0.5)
 }
+# generator arguments per workload (synthetic_scene.make_scene); absent: the benign room of SURVEY 8d
+SCENE_KW = {
+    "A1": dict(trajectory=True, room=(4.4, 3.5, 2.5), voxel_size=0.04),
+    "R2T": dict(trajectory=True),
+}
+SCENE_NAME = {"A1": "hand-held trajectory scene seed 0 (close-up dwells, opening in a wall and the ceiling, clutter 0.5; cell 0.04 m)",
+              "R2T": "hand-held trajectory scene seed 0 (close-up dwells, opening in a wall and the ceiling, clutter 0.5)"}
+
+
+def workload_scene(name, n_views=None, W=None, H=None):
+    """The synthetic scene of a named workload (n_views / W / H override the workload's: tests march reduced images)."""
+    from synthetic_scene import make_scene
+    n_vox, V, w, h, _ = WORKLOADS[name]
+    return make_scene(n_vox, n_views or V, W or w, H or h, seed=0, **SCENE_KW.get(name, {}))
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -59,7 +77,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["R4"],
                     help="R2 (default) = BASELINE metric config; R1 = config 2; S0 = config 1; R4 = config 5, the RGB path "
-                         "(500k voxels x 1000 views, uint8 images; its own kernel, no HBM-roofline claim)")
+                         "(500k voxels x 1000 views, uint8 images; its own kernel, no HBM-roofline claim); A1 = the problem size the "
+                         "reference's authors ran (87 319 voxels of 0.04 m x 216 views x 876x584x512) on a hand-held trajectory; R2T = "
+                         "the metric config's shape on a hand-held trajectory (close-up dwells, 29 %% of the rays miss, clutter 0.5)")
     ap.add_argument("--entry", default=None, choices=("parity", "fast"),
                     help="time the named entry point's in-process aggregation (VoxelFeatureAggregator.add_views over every "
                          "view of the workload, features resident) instead of raw C-ABI calls; default workload R1")
@@ -110,7 +130,10 @@ def parse():
                          "but does not remove the spread between processes")
     ap.add_argument("--heavy-threshold", type=int, default=0,
                     help="experiment: VP_OPT_HEAVY_THRESHOLD of the workspace (pixels per voxel and call above which a whole "
-                         "workgroup sums the voxel); 0 = the library's default, 256 + 64 x views per call")
+                         "workgroup sums the voxel); 0 = the library's default, min(256 + 64 x views per call, 1024)")
+    ap.add_argument("--part-pixels", type=int, default=0,
+                    help="experiment: VP_OPT_PART_PIXELS of the workspace (pixels per part of a voxel above the heavy threshold); "
+                         "0 = the library's default, min(2048, threshold / 2)")
     ap.add_argument("--march-lds-kb", type=int, default=-1,
                     help="experiment: VP_OPT_MARCH_LDS_KB of the workspace (dynamic-LDS reservation of the march = its occupancy "
                          "cap beside a gather); -1 = the library's default (41 KiB = 3 workgroups per CU)")
@@ -186,7 +209,7 @@ def write_pmc_json(prof_dir, out_path):
             for f in glob.glob(os.path.join(prof_dir, f"{kind}_{sfx}", "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     name = r["Kernel_Name"]
-                    k = "k_gather_heavy" if "k_gather_heavy" in name else "k_gather_one" if "k_gather_one" in name else "k_gather" if "k_gather" in name else \
+                    k = "k_combine_parts" if "k_combine_parts" in name else "k_gather_one" if "k_gather_one" in name else "k_gather" if "k_gather" in name else \
                         "k_first_hit" if "k_first_hit" in name else None
                     if k:
                         per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -397,7 +420,7 @@ def bench_entry(a, dev, rank, world, dist):
     n_vox, n_views, W, H, C = WORKLOADS[a.workload]
     if a.views:
         n_views = a.views
-    s = make_scene(n_vox, n_views, W, H, seed=0)
+    s = workload_scene(a.workload, n_views)
     my_views = views_of_rank(n_views, rank, world)
     pool = min(a.pool if a.pool != 32 else 128, len(my_views))
     feats = torch.empty((pool, H, W, C), dtype=torch.float32, device=dev)
@@ -481,14 +504,14 @@ def bench_entry(a, dev, rank, world, dist):
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{a.workload} through the entry point's aggregator, --mode {a.entry}: {n_vox} voxels x {n_views} "
-                                      f"views x {W}x{H}x{C} fp32 feature maps resident, room-shell scene seed 0",
+                                      f"views x {W}x{H}x{C} fp32 feature maps resident, {SCENE_NAME.get(a.workload, 'room-shell scene seed 0')}",
                           "views_per_call": per_call, "resident_feature_maps": pool,
                           "parallelism": f"views r::{world} per GPU + RCCL {a.collective}" if world > 1 else "single GPU"},
                "entry": {"mode": a.entry, "ms_per_view": round(ms_view, 4), "rows_out": n_out,
                          "dropin_ms_per_view": round(best * 1e3, 4), "entry_over_dropin": round(ms_view / (best * 1e3), 3),
                          "dropin_what": "project_features_cuda (compiled module), one view per blocking call"},
                "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3), "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
-                                     "gather": round(prof["gather_ms"] / a.steps, 3), "gather_heavy": round(prof["heavy_ms"] / a.steps, 3),
+                                     "gather": round(prof["gather_ms"] / a.steps, 3), "combine_parts": round(prof["heavy_ms"] / a.steps, 3),
                                      "note": "HIP events of an extra pass after the timed region"},
                "roofline": {"bound": "hbm", "kernel": "k_gather", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                             "avg_launch_ms": round(gather_ms, 4)}}
@@ -607,7 +630,7 @@ def main():
     n_vox, n_views, W, H, C = WORKLOADS[a.workload]
     if a.views:
         n_views = a.views
-    scene = make_scene(n_vox, n_views, W, H, seed=0)
+    scene = workload_scene(a.workload, n_views)
     from view_sharding import reduce_partials, views_of_rank
     my_views = views_of_rank(n_views, rank, world)
     esize = 4 if a.dtype == "f32" else 2
@@ -652,6 +675,8 @@ def main():
         ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, a.heavy_threshold)
     if a.march_lds_kb >= 0:
         ws.set_option(voxproj_host.VP_OPT_MARCH_LDS_KB, a.march_lds_kb)
+    if a.part_pixels > 0:
+        ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, a.part_pixels)
 
     # calls of one step: (pool slot of the first view, view indices)
     calls = []
@@ -679,6 +704,8 @@ def main():
             agg.ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, a.heavy_threshold)
         if a.march_lds_kb >= 0:
             agg.ws.set_option(voxproj_host.VP_OPT_MARCH_LDS_KB, a.march_lds_kb)
+        if a.part_pixels > 0:
+            agg.ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, a.part_pixels)
         intr4 = intr.reshape(4)                                     # device tensors: the caller's promise that they are ready
         c2ws = [c2w[vs].contiguous() for _, vs in calls]
         torch.cuda.synchronize(dev)
@@ -761,22 +788,34 @@ def main():
 
     # untimed pre-pass: algorithmic bytes of the dominant kernel per launch (deterministic across steps)
     hit_px, touched, gather_bytes, cnt, max_px, heavy_px = 0, 0, 0, {}, 0, 0
+    per_call = []
     out.zero_()
     for ci in range(len(calls)):
         count.zero_()
+        # alone on the device, HIP events around its kernels: what each call's march and gather do by themselves
+        voxproj_host.profile_enable(True)
         one_call(ci, sync=True)
+        pc = voxproj_host.profile_read()
+        voxproj_host.profile_enable(False)
         ph, nt = int(count.sum().item()), int((count > 0).sum().item())
         hit_px += ph
         touched += nt
-        # voxels above the library's per-call threshold (256 + 64*B*V pixels) are summed by the leading workgroups of
-        # the same k_gather launch: every hit pixel's row and every touched output row count for this kernel
-        heavy = count > (a.heavy_threshold or (256 + 64 * len(calls[ci][1])))
-        heavy_px += int(count[heavy].sum().item())
-        gather_bytes += ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
+        # voxels above the library's per-call threshold (min(256 + 64*B*V, 1024) pixels) are summed in parts by wavefronts of the same
+        # k_gather launch: every hit pixel's row and every touched output row count for this kernel
         c1 = voxproj_host.counters(ws, dev)
+        heavy = count > c1["heavy_t"]                  # the threshold in force: --heavy-threshold or min(256 + 64 * views per call, 1024)
+        heavy_px += int(count[heavy].sum().item())
+        bytes_call = ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
+        gather_bytes += bytes_call
         for k in c1:
-            cnt[k] = cnt.get(k, 0) + c1[k]
+            cnt[k] = max(cnt.get(k, 0), c1[k]) if k == "heavy_t" else cnt.get(k, 0) + c1[k]
         max_px = max(max_px, int(count.max().item()))
+        per_call.append({"views": len(calls[ci][1]), "hit_pixels": ph, "miss": round(1.0 - ph / float(len(calls[ci][1]) * H * W), 3),
+                         "touched": nt, "heavy": c1["n_heavy"], "parts": c1["n_parts"], "max_pixels_per_voxel": int(count.max().item()),
+                         "bytes": bytes_call})
+        if pc["gather_launches"] == 1:
+            per_call[-1].update(gather_ms_alone=round(pc["gather_ms"], 3), march_ms_alone=round(pc["first_hit_ms"], 3),
+                                frac_alone=round(bytes_call / (pc["gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
     ref_checksum = out.double().sum(0)       # plain (unpipelined) result of one full pass on this rank
     ref_abs = out.double().abs().sum(0)
@@ -901,7 +940,7 @@ def main():
             "dtype": "f32" if a.dtype == "f32" else "f32 accumulate, f16 feature maps",
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} {'fp32' if a.dtype == 'f32' else 'fp16'} feature maps, "
-                                   f"room-shell scene seed 0, dmin 0.01 dmax 10 step 0.5*voxel",
+                                   f"{SCENE_NAME.get(a.workload, 'room-shell scene seed 0')}, dmin 0.01 dmax 10 step 0.5*voxel",
                        "views_per_call": chunk, "resident_feature_maps": pool,
                        "parallelism": (f"views r::{world} per GPU + one RCCL {'reduce to rank 0' if a.collective == 'reduce' else 'all-reduce'} of sum/count "
                                        f"per pass, waited for inside the pass (backend {a.dist_backend})")
@@ -911,7 +950,7 @@ def main():
             "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
                                   "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
                                   "gather": round(prof["gather_ms"] / a.steps, 3),
-                                  "gather_heavy": round(prof["heavy_ms"] / a.steps, 3),
+                                  "combine_parts": round(prof["heavy_ms"] / a.steps, 3),
                                   "overlapped": pipeline},
             "pool_placement": placement, "device": device_info(dev), **reduced,
             **({"collective": {"op": "reduce to rank 0" if a.collective == "reduce" else "all-reduce", "backend": a.dist_backend,
@@ -926,7 +965,10 @@ def main():
                                        "rank's last call is cut into two row ranges and the first half's sums are reduced under the "
                                        "second half's gather; whole: the call as it is, then the collectives.  The arm that is not "
                                        "timed runs after the timed region, same number of steps"}} if dist is not None else {}),
-            "hit_pixels_per_step": hit_px, "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "heavy_pixels_per_step": heavy_px, "max_pixels_per_voxel_call": max_px,
+            "hit_pixels_per_step": hit_px, "miss_fraction": round(1.0 - hit_px / float(len(my_views) * H * W), 4),
+            "march_share_of_device_time": round(prof["first_hit_ms"] / max(1e-9, prof["first_hit_ms"] + prof["gather_ms"] + prof["heavy_ms"]), 4),
+            "box_miss_voxels": cnt["box_miss"], "heavy_voxels_per_step": cnt["n_heavy"], "heavy_pixels_per_step": heavy_px, "heavy_threshold": cnt["heavy_t"],
+            "parts_per_step": cnt["n_parts"], "max_pixels_per_voxel_call": max_px, "per_call": per_call,
             "roofline": {"bound": "hbm", "kernel": "k_gather", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "measured_stream_read_gbs": round(stream_gbs, 1),

@@ -57,8 +57,9 @@ enum {
                                 has been synchronised (vp_workspace_status does), and uses one stream per
                                 workspace.                                                            */
     VP_FLAG_SERIAL_SUMS = 32,  /* sum EVERY voxel with one wavefront in (b, v, y, x) order, however many pixels it got in
-                                the call: no voxel takes the four-wavefront heavy path, so all sums are bit-identical to the
-                                serial order of oracle/projector_oracle.c (the heavy path is within 1e-4, not bit-equal).
+                                the call: no voxel is split into parts (one view: shared by a workgroup), so all sums are
+                                bit-identical to the serial order of oracle/projector_oracle.c (split voxels are within 1e-4,
+                                not bit-equal).
                                 For callers that round the sums afterwards and promise the reference's bits -- the
                                 aggregator's parity mode (DPF:252 rounds to float16).  Slower only when a voxel is large. */
     VP_FLAG_GATHER_ONLY = 64,  /* phase 2 only: no ray-march; the first-hit images, the per-call histogram and the view table of
@@ -83,7 +84,7 @@ const char *vp_last_error(void);
 /*
  * Bytes of device scratch memory vp_project_features needs for a call of this shape
  * (first-hit ID image, per-call hit histogram, ID -> cell table, occupancy block masks and block
- * distance field, view table).
+ * distance field, view table, part slots of C floats for the split voxels' partial rows).
  */
 size_t vp_workspace_bytes(int B, int V, int H, int W, int C,
                           int dimz, int dimy, int dimx, int64_t n_rows);
@@ -178,8 +179,9 @@ int vp_workspace_status(void *workspace, void *stream);
  * Diagnostic counters of the last call on this workspace, copied to host_words[0..n) after a
  * stream synchronise: [0] = rays that hit an out-of-range ID, [1] = voxels whose search box
  * missed pixels and were rescanned over whole images (performance hint only; results are exact
- * either way), [2] = voxels summed by a whole workgroup because they collected more pixels than the
- * heavy threshold in this call.  No reference counterpart.
+ * either way), [2] = voxels that collected more pixels than the heavy threshold in this call (summed in
+ * parts; one-view calls: by a whole workgroup), [7] = the heavy threshold in force, [24] = the parts those
+ * voxels were cut into.  No reference counterpart.
  */
 int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream);
 
@@ -189,9 +191,9 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
  * vp_profile_enable(1) starts recording for subsequent vp_project_features calls of this process;
  * vp_profile_read synchronises the recorded events and returns, per kernel group, the summed
  * milliseconds and the number of launches: [0] = table preparation (memsets, occupancy tables, view
- * table), [1] = k_first_hit + work list + view table (phase 1), [2] = k_gather (phase 2; includes the heavy voxels when the call
- * has 8 or more views), [3] = k_gather_heavy (the heavy voxels' own launch in calls of fewer views); then clears
- * the record.
+ * table), [1] = k_first_hit + work list + view table (phase 1), [2] = k_gather / k_gather_one (phase 2, the parts of the split
+ * voxels included), [3] = k_combine_parts (the split voxels' partial rows added to their rows; calls of more than one view);
+ * then clears the record.
  */
 int vp_profile_enable(int on);
 int vp_profile_read(double *ms4, int64_t *launches4);
@@ -285,22 +287,30 @@ int vp_workspace_release(void *workspace);
 /*
  * Options of a workspace, read by the calls made on it (they replace the environment variables of ABI v2; the
  * library reads no environment variable).  value < 0 (or 0 for the threshold) restores the default.
- *   VP_OPT_HEAVY_THRESHOLD  voxels that collect more than this many pixels in ONE call are summed by a whole workgroup
- *                           (default 256 + 64*B*V; VP_FLAG_SERIAL_SUMS overrides it with "never")
+ *   VP_OPT_HEAVY_THRESHOLD  voxels that collect more than this many pixels in ONE call are not summed by a single wavefront: they
+ *                           are cut into parts of VP_OPT_PART_PIXELS pixels, each part summed by a wavefront of the same gather
+ *                           launch, the partial rows added to the voxel's row in a fixed order by a follow-up kernel (calls of
+ *                           ONE view: shared by the four wavefronts of a workgroup).  Default min(256 + 64*B*V, 1024) -- the
+ *                           longest job a wavefront can get bounds the tail of the launch --, 320 for calls of one view;
+ *                           VP_FLAG_SERIAL_SUMS overrides it with "never".  Never below the part size
+ *   VP_OPT_PART_PIXELS      pixels per part of a split voxel (default: the threshold); raised to 2*B*V*H*W / slots when the call
+ *                           is so large that its parts could outnumber the workspace's part slots (65536, fewer for rows wider
+ *                           than 2 KiB)
  *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
  *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a
  *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise).  Valid: 0 .. 64
  *                           (a kernel's dynamic-LDS limit); larger values are refused with VP_EINVAL
  *   VP_OPT_ROW_BEGIN / _END phase 2 of the following calls gathers only the voxel IDs in [begin, end) (default: all rows;
  *                           value < 0 restores it).  Phase 1 is not restricted: the histogram it leaves covers every row, so
- *                           that a VP_FLAG_GATHER_ONLY call can gather the other rows from it.  The list of heavy voxels is
- *                           the whole call's too: each ranged gather takes the listed IDs inside its own range, so every
- *                           voxel is summed by the same kernel role -- to the same bits -- as in the unsplit call
+ *                           that a VP_FLAG_GATHER_ONLY call can gather the other rows from it.  A voxel's parts depend on
+ *                           its pixel count and boxes alone, so each ranged gather sums every voxel of its range to the
+ *                           same bits as the unsplit call
  *   VP_OPT_ONE_VIEW_GATHER  0 = calls of ONE view (B*V == 1) go through the general gather kernel instead of the one-view
  *                           kernel (A/B arm; same results bit for bit); n > 0 = the one-view kernel with n workgroups per CU
  *                           (default 16; 1000 + g: exactly g workgroups, a test hook); < 0 restores the default
  */
-enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2, VP_OPT_ROW_BEGIN = 3, VP_OPT_ROW_END = 4, VP_OPT_ONE_VIEW_GATHER = 5 };
+enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2, VP_OPT_ROW_BEGIN = 3, VP_OPT_ROW_END = 4, VP_OPT_ONE_VIEW_GATHER = 5,
+       VP_OPT_PART_PIXELS = 6 };
 int vp_workspace_set_option(void *workspace, int option, long long value);
 
 /* How many times the occupancy-derived tables of this workspace have been (re)built so far (0 if never);

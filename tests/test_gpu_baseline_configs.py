@@ -1,12 +1,12 @@
 """GPU parity at the BASELINE.json configurations' OWN shapes, with the library's production settings
-(no heavy-threshold override: voxels above 256 + 64*B*V pixels per call take the workgroup path).
+(no heavy-threshold override: voxels above min(256 + 64*B*V, 1024) pixels per call are summed in parts).
 
   config 2  R1  ~80k voxels, 484x274x512 feature maps          -> 4 views in one call vs the oracle
   config 3  R2  200k voxels, 968x548x512 feature maps          -> 8 views in ONE call vs the oracle
   config 5  R4  500k voxels, uint8 [1168,1752,3] images (RGB)  -> 8 views vs oracle.rgb_project
 
 Bar (north_star): first-hit voxel IDs and hit counts bit-exact; feature sums of voxels summed by one wavefront
-bit-identical to the oracle's serial (b,v,y,x) order; sums of heavy voxels (fixed workgroup tree) within 1e-4 of the
+bit-identical to the oracle's serial (b,v,y,x) order; sums of split voxels (parts combined in a fixed order) within 1e-4 of the
 oracle's float64 accumulation, per element, relative to that voxel row's own magnitude (max_c |sum|) -- and strictly
 relative per element wherever the element is not a cancellation residue (|sum| >= 1 % of the row's magnitude).
 RGB: float32 colour sums, view counts, first views and pixel indices bit-exact.
@@ -72,7 +72,8 @@ def _feature_config(oracle_mod, n_vox, n_views_scene, W, H, C, views, min_heavy)
     assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
     ctr = voxproj_host.counters(ws, dev)
     assert ctr["bad_id"] == 0 and ctr["box_miss"] == 0
-    heavy_t = 256 + 64 * 1 * V                              # voxproj.hip: the production threshold
+    heavy_t = ctr["heavy_t"]
+    assert heavy_t == min(256 + 64 * 1 * V, 1024)           # voxproj.hip: the production threshold
     heavy = count > heavy_t
     assert ctr["n_heavy"] == int(heavy.sum()) >= min_heavy, (ctr, int(heavy.sum()))
     got = out_t.cpu().numpy()
@@ -132,7 +133,7 @@ def test_config5_rgb_500k_voxels_eight_views_vs_oracle(oracle_mod):
 
 def test_config3_full_300_view_pipelined_pass_counts_vs_oracle(oracle_mod):
     # The WHOLE metric workload the way bench.py drives it -- 300 views cut into calls by bench.plan_calls itself (today:
-    # five pipelined calls of 60 views, 65 GB of maps resident, heavy threshold 256 + 64 * 60 = 4096 pixels), production
+    # five pipelined calls of 60 views, 65 GB of maps resident, heavy threshold min(256 + 64 * 60, 1024) pixels), production
     # heavy-voxel threshold, the resident pool cycled -- against the oracle's ray-march of all 300 views: per-voxel pixel
     # counts and per-voxel view counts bit-exact.  The feature sums (326 GB of rows) cannot be replayed on the host; they
     # are checked through a checksum of checksums: per channel, the sum over all voxel rows must equal the sum of the
@@ -245,7 +246,8 @@ def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
     count_ref[0] = 0
     got_c = count_t.cpu().numpy().astype(np.int64)
     assert np.array_equal(got_c, count_ref) and np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
-    heavy_t = 256 + 64 * V
+    heavy_t = ctr["heavy_t"]
+    assert heavy_t == 1024                                               # voxproj.hip: min(256 + 64 * B * V, 1024)
     heavy = torch.from_numpy(count_ref > heavy_t).to(dev)
     assert ctr["n_heavy"] == int(heavy.sum().item()) > 0 and int(count_ref.max()) > heavy_t
     ref[0] = 0

@@ -1,0 +1,325 @@
+"""GPU parity AWAY from the benign room: the problem size the reference's authors ran (A1: 87 319 voxels of
+0.04 m x 216 views x 876x584x512, aggregate_voxel_features_onthefly.py:18,28,106,209) and the metric config's shape (R2T), both
+on the hand-held trajectory of synthetic_scene.make_scene(trajectory=True): consecutive frames a few centimetres apart, close-up
+dwells 0.27 m in front of a wall (single voxels collect 10^5 pixels in a call), an opening in a wall and the ceiling (29-37 % of
+the rays miss), clutter fraction 0.5.  Production thresholds, the call plan bench.plan_calls makes.
+
+Bar (north_star): first-hit voxel IDs, pixel counts and view counts bit-exact against the oracle; feature sums of voxels summed by
+one wavefront bit-identical to the oracle's serial (b,v,y,x) order; sums of SPLIT voxels (parts combined in slot order, a fixed
+tree) within 1e-4 of the float64 accumulation, per element, relative to the row's magnitude -- and strictly per element wherever
+the element is not a cancellation residue (|sum| >= 1 % of the row's magnitude)."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from synthetic_scene import make_features_np, make_features_torch, make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_module():
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    return m
+
+
+def _rows_within_bar(got, ref64, rows):
+    """rows of got (f32) vs ref64 (f64): 1e-4 of the row's magnitude per element, strictly per element off the residues."""
+    err = np.abs(got[rows].astype(np.float64) - ref64[rows])
+    row_mag = np.abs(ref64[rows]).max(axis=1, keepdims=True)
+    assert (err <= 1e-4 * row_mag).all(), float((err / row_mag).max())
+    solid = np.abs(ref64[rows]) >= 1e-2 * row_mag
+    assert (err[solid] <= 1e-4 * np.abs(ref64[rows])[solid]).all()
+    return float((err / row_mag).max())
+
+
+@pytest.mark.parametrize("name,views", [
+    ("A1", [0, 1, 2, 3, 104, 105, 130, 131]),        # four frames of the first close-up dwell, the walk, the look through the opening
+    ("R2T", [20, 21, 22, 23, 24, 25, 150, 260]),
+])
+def test_trajectory_shapes_eight_views_one_call_vs_oracle(oracle_mod, name, views):
+    import voxproj_host
+    bm = _bench_module()
+    dev = torch.device(DEV)
+    n_vox, n_views, W, H, C = bm.WORKLOADS[name]
+    s = bm.workload_scene(name)
+    assert s.n_vox == n_vox and s.n_views == n_views and (s.width, s.height) == (W, H)
+    V = len(views)
+    feats_t = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(V, H, W, C, dev, seed=5, out=feats_t[0])
+    feats = feats_t.cpu().numpy()
+    c2w = np.ascontiguousarray(s.c2w[views])
+    n_rows = n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    r = oracle_mod.project_features(feats, s.occ[None].astype(np.int64), c2w.reshape(-1), s.intr[None], s.opts(),
+                                    s.grid_origin, s.voxel_size, count, out, want_f64=True)
+    assert r["rc"] == 0
+    del feats
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    ws = voxproj_host.project_features_raw(
+        feats_t, torch.from_numpy(s.occ[None].astype(np.int64)).to(dev), torch.from_numpy(c2w).reshape(-1).to(dev),
+        torch.from_numpy(s.intr[None]).to(dev), [float(v) for v in s.opts()], count_t, out_t,
+        [float(v) for v in s.grid_origin], s.voxel_size, sync=True, views_hit=views_t)
+    hits = voxproj_host.hit_image(ws, dev).cpu().numpy()
+    assert np.array_equal(hits, r["hits"]), f"first-hit IDs differ at {(hits != r['hits']).sum()} pixels"
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    views_ref = np.zeros(n_rows, np.int64)
+    for v in range(V):
+        ids = np.unique(r["hits"][0, v])
+        views_ref[ids[ids > 0]] += 1
+    assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
+    ctr = voxproj_host.counters(ws, dev)
+    assert ctr["bad_id"] == 0 and ctr["box_miss"] == 0
+    assert ctr["heavy_t"] == min(256 + 64 * V, 1024)            # the production threshold, not raised by the part-slot bound here
+    heavy = count > ctr["heavy_t"]
+    assert ctr["n_heavy"] == int(heavy.sum()) > 20, (ctr, int(heavy.sum()))
+    assert ctr["n_parts"] >= 2 * ctr["n_heavy"]
+    miss = float((r["hits"] == 0).mean())
+    assert 0.05 < miss < 0.6, miss                              # some of these frames look through the opening
+    assert int(count.max()) > 8 * ctr["heavy_t"]                # a close-up: single voxels far above the threshold
+    got = out_t.cpu().numpy()
+    assert got[~heavy].tobytes() == out[~heavy].tobytes(), "one-wavefront rows must equal the oracle's serial fp32 sums"
+    _rows_within_bar(got, r["out64"], heavy)
+
+
+def test_a1_whole_216_view_pass_counts_vs_oracle(oracle_mod):
+    """The authors' problem size the way bench.py drives it (plan_calls: four pipelined calls of 54 views, resident maps cycled),
+    production thresholds: per-voxel pixel counts and view counts bit-exact against the oracle's march of all 216 views; the
+    feature sums through a checksum of checksums evaluated from the ORACLE's first-hit images in float64."""
+    import voxproj_host
+    bm = _bench_module()
+    dev = torch.device(DEV)
+    n_vox, n_views, W, H, C = bm.WORKLOADS["A1"]
+    chunk, n_calls, resident = bm.plan_calls(n_views, H, W, C, 4)
+    assert chunk * n_calls >= n_views and resident == chunk
+    s = bm.workload_scene("A1")
+    n_rows = n_vox + 1
+    occ64 = s.occ[None].astype(np.int64)
+    pool = torch.empty((1, chunk, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(chunk, H, W, C, dev, seed=0, out=pool[0])
+    occ_t = torch.from_numpy(occ64).to(dev)
+    c2w_t = torch.from_numpy(s.c2w).to(dev)
+    intr_t = torch.from_numpy(s.intr[None]).to(dev)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    ws = voxproj_host.Workspace()
+    opts, origin = [float(v) for v in s.opts()], [float(v) for v in s.grid_origin]
+    vmis, n_heavy, n_parts = [], 0, 0
+    for a in range(0, n_views, chunk):
+        b = min(n_views, a + chunk)
+        vmis.append(c2w_t[a:b].reshape(-1).contiguous())
+        voxproj_host.project_features_raw(pool[:, :b - a], occ_t, vmis[-1], intr_t, opts, count_t, out_t, origin, s.voxel_size,
+                                          workspace=ws, sync=False, reuse_accel=(a > 0 or None), pipeline=True, views_hit=views_t)
+    voxproj_host.workspace_status(ws, dev)
+    ctr = voxproj_host.counters(ws, dev)
+    assert ctr["bad_id"] == 0 and ctr["box_miss"] == 0
+    count_ref = np.zeros(n_rows, np.int64)
+    views_ref = np.zeros(n_rows, np.int64)
+    tot = torch.zeros(C, dtype=torch.float64, device=dev)
+    tot_abs = torch.zeros(C, dtype=torch.float64, device=dev)
+    biggest = 0
+    sub = 18
+    for a in range(0, n_views, sub):
+        b = min(n_views, a + sub)
+        hits = oracle_mod.first_hit(occ64, s.c2w[a:b].reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, 1, b - a)
+        count_ref += np.bincount(hits.reshape(-1), minlength=n_rows)
+        for v in range(b - a):
+            ids = np.unique(hits[0, v])
+            views_ref[ids[ids > 0]] += 1
+        mask = torch.from_numpy(hits[0] > 0).to(dev)
+        for v in range(b - a):
+            rows = pool[0, (a + v) % chunk][mask[v]].double()
+            tot += rows.sum(0)
+            tot_abs += rows.abs().sum(0)
+    count_ref[0] = 0
+    assert np.array_equal(count_t.cpu().numpy().astype(np.int64), count_ref)
+    assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
+    miss = 1.0 - count_ref.sum() / float(n_views * H * W)
+    assert 0.2 < miss < 0.45, miss
+    assert int(count_ref.max()) > 100000                        # the close-up dwell: one voxel, > 10^5 pixels over the pass
+    assert ((out_t.double().sum(0) - tot).abs() <= 1e-6 * tot_abs).all()
+
+
+def test_r2t_close_up_call_rows_vs_float64_reference(oracle_mod):
+    """The first call of the R2T bench leg -- 60 consecutive frames of the close-up dwell: ~400 voxels share 32 M pixels, single
+    voxels collect more than 10^5 -- row by row against a reference no HIP gather touched (the ORACLE's first-hit images and,
+    per view, index_add_ of the hit pixels' rows in float64 on the device).  Every row within 1e-4 of its magnitude and per
+    element off the cancellation residues; pixel counts and view counts exact; two runs bit-identical (the parts are combined
+    in a fixed order, whichever wavefront finishes first)."""
+    import voxproj_host
+    bm = _bench_module()
+    dev = torch.device(DEV)
+    n_vox, n_views, W, H, C = bm.WORKLOADS["R2T"]
+    V, n_calls, _ = bm.plan_calls(n_views, H, W, C, 4)
+    assert V >= 32
+    s = bm.workload_scene("R2T")
+    n_rows = n_vox + 1
+    occ64 = s.occ[None].astype(np.int64)
+    feats = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    occ_t, intr_t = torch.from_numpy(occ64).to(dev), torch.from_numpy(s.intr[None]).to(dev)
+    opts, origin = [float(v) for v in s.opts()], [float(v) for v in s.grid_origin]
+    ws = voxproj_host.Workspace()
+    views = list(range(V))
+    vmi = torch.from_numpy(s.c2w[views]).reshape(-1).contiguous().to(dev)
+
+    def call():
+        count_t.zero_(); views_t.zero_(); out_t.zero_()
+        voxproj_host.project_features_raw(feats, occ_t, vmi, intr_t, opts, count_t, out_t, origin, s.voxel_size, workspace=ws,
+                                          sync=True, views_hit=views_t)
+        c = voxproj_host.counters(ws, dev)
+        assert c["bad_id"] == 0 and c["box_miss"] == 0
+        return c
+
+    ctr = call()
+    first = out_t.clone()
+    ctr2 = call()
+    assert ctr == ctr2 and torch.equal(first, out_t), "two runs of the same call must leave the same bits"
+    del first
+    ref = torch.zeros(n_rows, C, dtype=torch.float64, device=dev)
+    count_ref = np.zeros(n_rows, np.int64)
+    views_ref = np.zeros(n_rows, np.int64)
+    sub = 20
+    for a in range(0, V, sub):
+        b = min(V, a + sub)
+        hits = oracle_mod.first_hit(occ64, s.c2w[views[a:b]].reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, 1, b - a)
+        count_ref += np.bincount(hits.reshape(-1), minlength=n_rows)
+        for v in range(b - a):
+            ids_np = np.unique(hits[0, v])
+            views_ref[ids_np[ids_np > 0]] += 1
+            ids = torch.from_numpy(hits[0, v].reshape(-1).astype(np.int64)).to(dev)
+            rows = feats[0, a + v].reshape(-1, C).double()
+            ref.index_add_(0, ids, rows)
+            del rows
+    count_ref[0] = 0
+    assert np.array_equal(count_t.cpu().numpy().astype(np.int64), count_ref)
+    assert np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
+    heavy_np = count_ref > ctr["heavy_t"]
+    assert ctr["n_heavy"] == int(heavy_np.sum()) > 100 and int(count_ref.max()) > 100000, (ctr, int(count_ref.max()))
+    assert ctr["heavy_t"] == 1024 and ctr["n_parts"] > 20000      # 32 M pixels in parts of <= 1024
+    ref[0] = 0
+    err = (out_t.double() - ref).abs()
+    row_mag = ref.abs().max(dim=1, keepdim=True).values
+    touched = torch.from_numpy(count_ref > 0).to(dev)
+    assert float(out_t[~touched].abs().max().item()) == 0.0
+    rel_row = err[touched] / row_mag[touched]
+    assert float(rel_row.max().item()) <= 1e-4, float(rel_row.max().item())
+    # per element: where the element is at least 1 % of the row's magnitude for rows of up to 32768 addends, 10 % for longer
+    # ones -- with 10^5 float32 addends per element (|addend| ~ 0.04, partial sums of parts ~ 2) the accumulated rounding is
+    # ~1e-5 absolute whatever the order (the reference's own atomics in arrival order: ~1e-3), i.e. 1e-4 of an element of 0.1
+    long_rows = torch.from_numpy(count_ref > 32768).to(dev)[:, None]
+    solid = touched[:, None] & (ref.abs() >= torch.where(long_rows, 1e-1 * row_mag, 1e-2 * row_mag))
+    assert float((err[solid] / ref.abs()[solid]).max().item()) <= 1e-4
+
+
+@pytest.mark.parametrize("B,V,part_px,heavy_t,half", [
+    (1, 2, 1, 3, False), (1, 5, 2, 6, False), (1, 9, 7, 6, True), (2, 3, 5, 20, False), (1, 70, 64, 100, False),
+    (2, 40, 16, 40, True), (1, 12, 100000, 50, False),
+])
+def test_split_voxels_parts_of_every_size_against_the_oracle(oracle_mod, B, V, part_px, heavy_t, half):
+    """VP_OPT_PART_PIXELS / VP_OPT_HEAVY_THRESHOLD from one pixel per part upwards, batches, more than 64 views (two view groups
+    per part), fp16 maps, C not a multiple of the vector width: IDs, counts and view counts exact, sums within the bar, parts
+    planned as the options say (P = ceil(c / part_px) per voxel above the threshold), two runs bit-identical."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    C = 24 if half else 20
+    s = make_scene(2000, B * V, 48, 32, seed=500 + V, room=(5.0, 4.0, 2.4))
+    s2 = make_scene(2000, B * V, 48, 32, seed=600 + V, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(B * V, 32, 48, C, seed=77).reshape(B, V, 32, 48, C)
+    if half:
+        feats = feats.astype(np.float16).astype(np.float32)
+    occ = np.stack([s.occ, s.occ][:B]).astype(np.int64)          # batch 1: the same grid from other cameras and intrinsics
+    c2w = s.c2w.copy()
+    if B == 2:
+        c2w[V:] = s2.c2w[V:]
+    intr = np.stack([s.intr, s.intr * np.float32(0.9)][:B])
+    n_rows = s.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    r = oracle_mod.project_features(feats, occ, c2w.reshape(-1), intr, s.opts(), s.grid_origin, s.voxel_size, count, out, want_f64=True)
+    assert r["rc"] == 0
+    ws = voxproj_host.Workspace()
+    ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, heavy_t)
+    ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, part_px)
+    feats_t = torch.from_numpy(feats).to(dev)
+    if half:
+        feats_t = feats_t.half()
+    occ_t, c2w_t, intr_t = torch.from_numpy(occ).to(dev), torch.from_numpy(c2w).reshape(-1).to(dev), torch.from_numpy(intr).to(dev)
+    res = []
+    for rep in range(2):
+        count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        out_t = torch.zeros(n_rows, C, device=dev)
+        views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        voxproj_host.project_features_raw(feats_t, occ_t, c2w_t, intr_t, [float(v) for v in s.opts()], count_t, out_t,
+                                          [float(v) for v in s.grid_origin], s.voxel_size, workspace=ws, sync=True, views_hit=views_t)
+        res.append((count_t.cpu().numpy(), out_t.cpu().numpy(), views_t.cpu().numpy()))
+    ctr = voxproj_host.counters(ws, dev)
+    hits = voxproj_host.hit_image(ws, dev).cpu().numpy()
+    assert np.array_equal(hits, r["hits"])
+    assert np.array_equal(res[0][0], count) and res[0][1].tobytes() == res[1][1].tobytes()
+    views_ref = np.zeros(n_rows, np.int64)
+    for b in range(B):
+        for v in range(V):
+            ids = np.unique(r["hits"][b, v])
+            views_ref[ids[ids > 0]] += 1
+    assert np.array_equal(res[0][2].astype(np.int64), views_ref)
+    t_eff = ctr["heavy_t"]
+    px_eff = max(part_px, 1)
+    assert t_eff == max(heavy_t, px_eff), ctr                   # raised to the part size only (the slot bound is below it here)
+    heavy = count > t_eff
+    assert ctr["n_heavy"] == int(heavy.sum()) and ctr["box_miss"] == 0
+    if part_px <= heavy_t:
+        assert ctr["n_heavy"] > 0
+        assert ctr["n_parts"] == int(np.ceil(count[heavy] / float(px_eff)).sum()), ctr
+    got = res[0][1]
+    assert got[~heavy].tobytes() == out[~heavy].tobytes()
+    if heavy.any():
+        _rows_within_bar(got, r["out64"], heavy)
+
+
+def test_split_voxels_whose_boxes_miss_pixels_are_redone_over_whole_images(oracle_mod):
+    """An ID that labels several cells: the search boxes (built around ONE of them) miss the other cells' pixels.  For a split
+    voxel the parts then add up to fewer pixels than the march counted; k_combine_parts redoes the voxel over whole images."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 6, 48, 32, seed=71, room=(5.0, 4.0, 2.4))
+    occ = np.where(s.occ > 0, (s.occ % 5) + 1, 0).astype(np.int64)[None]
+    C = 12
+    feats = make_features_np(6, 32, 48, C, seed=72)[None]
+    n_rows = 7
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    r = oracle_mod.project_features(feats, occ, s.c2w.reshape(-1), s.intr[None], s.opts(), s.grid_origin, s.voxel_size, count, out, want_f64=True)
+    ws = voxproj_host.Workspace()
+    ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, 64)
+    ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 32)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    views_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    voxproj_host.project_features_raw(torch.from_numpy(feats).to(dev), torch.from_numpy(occ).to(dev), torch.from_numpy(s.c2w).reshape(-1).to(dev),
+                                      torch.from_numpy(s.intr[None]).to(dev), [float(v) for v in s.opts()], count_t, out_t,
+                                      [float(v) for v in s.grid_origin], s.voxel_size, workspace=ws, sync=True, views_hit=views_t)
+    ctr = voxproj_host.counters(ws, dev)
+    assert ctr["n_heavy"] == 5 and ctr["box_miss"] == 5 and ctr["n_parts"] > 10, ctr
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    assert (views_t.cpu().numpy()[1:6] == 6).all()
+    _rows_within_bar(out_t.cpu().numpy(), r["out64"], count > 0)
