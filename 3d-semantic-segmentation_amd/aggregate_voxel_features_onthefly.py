@@ -87,21 +87,28 @@ class VoxelFeatureAggregator:
             self._reported = 0
         else:
             self.sum32 = torch.zeros(n, C, dtype=torch.float32, device=self.dev)
-            self.count = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            # every integer the scene's collective moves lives in ONE tensor (round 5): pixel counts, view counts and, in a
+            # spare slot behind them, the number of views seen -- a multi-rank pass issues the feature sums (one piece, or two
+            # when the last call is cut) plus ONE integer collective instead of three
+            pad = (n + 63) & ~63
+            self._ints = torch.zeros(2 * pad + 64, dtype=torch.int32, device=self.dev)
+            self.count = self._ints[:n]
+            self.views = self._ints[pad:pad + n]
+            self._n_seen_slot = self._ints[2 * pad:2 * pad + 1]
 
     def reset(self):
         """Forget every view seen so far (the occupancy grid, its derived tables and the workspace stay)."""
         self.flush()
         self.n_seen = 0
-        self.views.zero_()
-        if self.mode == "parity":
-            self.run16.zero_()
-            self.first_view.fill_(_NEVER)
-            self._nonfinite.zero_()
-            self._reported = 0
-        else:
+        if self.mode != "parity":
             self.sum32.zero_()
-            self.count.zero_()
+            self._ints.zero_()
+            return
+        self.views.zero_()
+        self.run16.zero_()
+        self.first_view.fill_(_NEVER)
+        self._nonfinite.zero_()
+        self._reported = 0
 
     def _opts(self, W, H):
         return [float(W), float(H), 0.01, 10.0, float(np.float32(self.voxel_size * 0.5))]   # DPF:167-169
@@ -221,13 +228,23 @@ class VoxelFeatureAggregator:
             if staged is not None:
                 self._project_fast(staged[0], staged[1], staged[2], gather_only=gather_only)
 
-        h = project_final_call_and_reduce(dist, project, self.ws.set_row_range, [self.sum32], [self.count, self.views], self.n_rows,
+        self._n_seen_slot.fill_(self.n_seen)             # rides in the integer tensor's spare slot
+        h = project_final_call_and_reduce(dist, project, self.ws.set_row_range, [self.sum32], [self._ints], self.n_rows,
                                           dst=dst, split=split, on_projected=on_projected)
         self.flush()
-        n = torch.tensor([self.n_seen], device=self.dev)
-        reduce_partials(dist, [n])
-        self.n_seen = int(n.item())
+        self._finish_n_seen(dist, dst)
         return h
+
+    def _finish_n_seen(self, dist, dst):
+        """The number of views all ranks have seen: from the integer tensor's spare slot where the collective left the scene
+        (all-reduce: everywhere; reduce: on rank ``dst``), broadcast from there otherwise."""
+        from view_sharding import reduce_partials
+        if dst is None:
+            self.n_seen = int(self._n_seen_slot.item())
+        else:
+            n = self._n_seen_slot.clone() if dist.get_rank() == dst else torch.zeros(1, dtype=torch.int32, device=self.dev)
+            reduce_partials(dist, [n])                   # only the root's slot holds the total; the others contribute zero
+            self.n_seen = int(n.item())
 
     def flush(self):
         """Drain the stream, surface device-side errors, and (parity mode) report the views whose float16 rows held a
@@ -242,17 +259,17 @@ class VoxelFeatureAggregator:
             self._reported = self.n_seen
 
     def all_reduce(self, dst=None):
-        """Combine the ranks' partial {sum, count, views} (fast mode): one SUM collective per tensor over RCCL.
+        """Combine the ranks' partial {sum, count, views} (fast mode): one SUM collective for the feature sums and one for the
+        integers (pixel counts, view counts, views seen -- one tensor) over RCCL.
         ``dst=None`` all-reduces (every rank holds the scene), ``dst=0`` reduces to rank 0 only -- half the traffic, and
         enough when rank 0 alone writes the files (main() does that).  The number of views seen is always all-reduced."""
         import torch.distributed as dist
         assert self.mode != "parity", "the parity mode is order-dependent (fp16 running sums) and stays on one GPU"
         from view_sharding import reduce_partials
         self.flush()
-        n = torch.tensor([self.n_seen], device=self.dev)
-        reduce_partials(dist, [self.sum32, self.count, self.views], dst=dst)
-        reduce_partials(dist, [n])
-        self.n_seen = int(n.item())
+        self._n_seen_slot.fill_(self.n_seen)
+        reduce_partials(dist, [self.sum32, self._ints], dst=dst)      # the sums and ONE integer tensor {count, views, n_seen}
+        self._finish_n_seen(dist, dst)
 
     def result(self, xyz_dtype=np.float32):
         """Consolidated tensors in the reference's schema (AGG:381-451)."""

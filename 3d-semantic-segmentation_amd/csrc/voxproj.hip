@@ -281,13 +281,15 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // ---- phase 1 (on s1) ----
     // More pixels than heavy_t in one call -> the voxel is not one wavefront's job.  One-view calls: a workgroup of the same
     // launch sums it (k_gather_one), threshold 256 + 64.  Every other call cuts it into parts of part_px pixels (vp_gather.h,
-    // "Split voxels"), and both numbers default to min(256 + 64*B*V, 1024): the longest item a wavefront can be handed bounds
-    // the tail of the launch -- the last items run on an emptying machine at ~4 GB/s per wavefront, 1024 rows of 2 KiB in half
-    // a millisecond.  On the close-up call of the R2T leg (60 frames staring at a wall from 0.27 m: 32 M pixels in 400 voxels,
-    // every one of them split): threshold / part 4096 / 2048 -> 11.7 ms, 2048 / 2048 -> 10.75, 1024 / 1024 -> 10.17 (0.70 / 0.76 /
-    // 0.80 of peak, one allocation, profiles/r05_ab_split_voxels.log); a call that is mostly misses, whose 2.8 ms were its
-    // longest voxel: 0.59 -> 0.79.
-    int heavy_t = (int)std::min<long long>(256 + 64ll * B * V, 1024);
+    // "Split voxels"), and both numbers default to min(256 + 64*B*V, 2048): the longest item a wavefront can be handed bounds
+    // the tail of the launch -- the last items run on an emptying machine at ~4 GB/s per wavefront, 2048 rows of 2 KiB in a
+    // millisecond.  On the close-up call of the R2T leg (60 frames staring at a wall from 0.27 m: 32 M pixels in 400 voxels,
+    // every one of them split), alone on the device: threshold / part 4096 / 2048 -> 11.5-11.7 ms, 2048 / 2048 -> 10.6-10.75,
+    // 1024 / 1024 -> 10.2-10.9, 512 / 512 -> 10.85 (0.70 / 0.76-0.77 / 0.75-0.80 / 0.75 of peak, two boxes, one allocation each);
+    // a call that is mostly misses, whose 2.8 ms were its longest voxel: 0.59 -> 0.75-0.77.  Whole pipelined passes: R2T 42.65 ->
+    // 41.40 ms with 2048 / 2048 (1024 / 1024: 41.45), the benign R2 room 55.58 -> 55.54 (1024 / 1024: 55.9: 12 k parts per call
+    // where 1.2 k do) -- profiles/r05_ab_split_voxels.log.
+    int heavy_t = (int)std::min<long long>(256 + 64ll * B * V, 2048);
     if ((long long)B * V == 1) heavy_t = 256 + 64;
     if (rec.opt_heavy_t > 0) heavy_t = (int)std::min<long long>(rec.opt_heavy_t, 2147483647ll);   // VP_OPT_HEAVY_THRESHOLD
     if (flags & VP_FLAG_SERIAL_SUMS) heavy_t = 2147483647;
@@ -298,7 +300,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // The parts' partial rows live in the buffer set's part slots, and a call's parts must never outnumber them: a split voxel
     // has c > heavy_t >= part_px pixels and P = ceil(c / part_px) <= 2c / part_px parts, the c of a call add up to at most
     // B*V*H*W, so part_px >= 2*B*V*H*W / slots is enough -- both values are raised to that bound (only calls larger than the
-    // bench's are: 65536 slots allow parts of 1024 pixels up to 33.5 M pixels per call).
+    // bench's are: 32768 slots allow parts of 2048 pixels up to 33.5 M pixels per call).
     int part_px = 0;
     if (!one_view && heavy_t != 2147483647) {
         long long ppx = rec.opt_part_px > 0 ? rec.opt_part_px : std::max<long long>(1, heavy_t);     // VP_OPT_PART_PIXELS

@@ -296,10 +296,10 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 // Part slots of one buffer set (split voxels, vp_gather.h): a voxel above the heavy threshold is summed as P parts, each
 // part's C-wide partial row in a slot.  The number of slots bounds how finely a call can be cut: with part_px >= 2*B*V*H*W /
 // slots and heavy_t >= part_px the parts of a call can never outnumber the slots (project_impl raises both to that bound).
-// 65536 slots -- parts of 1024 pixels for calls of up to 33 M pixels (60 views of 968x548) --, fewer when the rows are wide
-// (128 MiB of partial rows per set at most) or the call is small.
+// 32768 slots -- parts of 2048 pixels for calls of up to 33 M pixels (60 views of 968x548) --, fewer when the rows are wide
+// (64 MiB of partial rows per set at most) or the call is small.
 #ifndef VP_MAX_SLOTS
-#define VP_MAX_SLOTS 65536
+#define VP_MAX_SLOTS 32768
 #endif
 inline long long part_slot_cap(int B, int V, int H, int W, int C)
 {

@@ -381,7 +381,7 @@ def hit_image(ws, device):
 
 def counters(ws, device):
     """Device-side diagnostic counters of the last call: dict(bad_id, box_miss, n_heavy, heavy_t, n_parts) -- n_heavy = voxels
-    above the heavy threshold in force (heavy_t: the option or min(256 + 64*B*V, 1024), raised to the part-slot bound where that binds),
+    above the heavy threshold in force (heavy_t: the option or min(256 + 64*B*V, 2048), raised to the part-slot bound where that binds),
     n_parts = the parts they were cut into (0 for one-view calls, whose heavy voxels a workgroup sums)."""
     import torch
     arr = (ctypes.c_int32 * 32)()

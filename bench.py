@@ -130,7 +130,7 @@ def parse():
                          "but does not remove the spread between processes")
     ap.add_argument("--heavy-threshold", type=int, default=0,
                     help="experiment: VP_OPT_HEAVY_THRESHOLD of the workspace (pixels per voxel and call above which a whole "
-                         "workgroup sums the voxel); 0 = the library's default, min(256 + 64 x views per call, 1024)")
+                         "workgroup sums the voxel); 0 = the library's default, min(256 + 64 x views per call, 2048)")
     ap.add_argument("--part-pixels", type=int, default=0,
                     help="experiment: VP_OPT_PART_PIXELS of the workspace (pixels per part of a voxel above the heavy threshold); "
                          "0 = the library's default, min(2048, threshold / 2)")
@@ -144,6 +144,10 @@ def parse():
                     help="multi-rank step: the TIMED arm does not cut the pass's last call into two row ranges (VP_OPT_ROW_BEGIN/_END "
                          "+ VP_FLAG_GATHER_ONLY) whose first half is all-reduced under the second half's gather.  Either way the "
                          "other arm is run after the timed region and both are reported (collective.arms)")
+    ap.add_argument("--collective-arm", default="auto", choices=("auto", "split", "whole"),
+                    help="multi-rank step: which collective arm the timed region runs.  auto (default) = a short untimed calibration "
+                         "of both arms (2 steps each, MAX over ranks) picks the faster one; the other arm runs after the timed "
+                         "region either way and both are reported (collective.arms, collective.calibration)")
     ap.add_argument("--no-other-arm", action="store_true",
                     help="multi-rank step: skip the steps of the other collective arm after the timed region")
     ap.add_argument("--launch-check", action="store_true",
@@ -759,10 +763,11 @@ def main():
     # The timed region runs the default arm (split; --no-split-collective: whole), the other arm runs after it for the same
     # number of steps, and the line carries both (collective.arms).  collective_ms_exposed = pass - (zeroing + projection),
     # the latter from HIP events around it.
-    state = {"exposed_s": 0.0}
+    state = {"exposed_s": 0.0, "proj_s": 0.0}
     dst = 0 if a.collective == "reduce" else None
     h_rows = split_point(n_rows) if dist is not None else 0
-    default_split = dist is not None and not a.no_split_collective and h_rows > 0
+    arm_arg = "whole" if a.no_split_collective else a.collective_arm
+    default_split = dist is not None and arm_arg != "whole" and h_rows > 0       # "auto": decided by the calibration below
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def step_dist(split_arm):
@@ -776,7 +781,9 @@ def main():
         slot, vs = calls[last]
         agg.add_final_views(feats[0, slot:slot + len(vs)], c2ws[last], intr4, dst=dst, split=split_arm, on_projected=ev_b.record)
         torch.cuda.synchronize(dev)
-        state["exposed_s"] += (time.perf_counter() - t_a) - ev_a.elapsed_time(ev_b) * 1e-3
+        proj = ev_a.elapsed_time(ev_b) * 1e-3
+        state["proj_s"] += proj
+        state["exposed_s"] += (time.perf_counter() - t_a) - proj
 
     def step():
         if dist is not None:
@@ -800,10 +807,10 @@ def main():
         ph, nt = int(count.sum().item()), int((count > 0).sum().item())
         hit_px += ph
         touched += nt
-        # voxels above the library's per-call threshold (min(256 + 64*B*V, 1024) pixels) are summed in parts by wavefronts of the same
+        # voxels above the library's per-call threshold (min(256 + 64*B*V, 2048) pixels) are summed in parts by wavefronts of the same
         # k_gather launch: every hit pixel's row and every touched output row count for this kernel
         c1 = voxproj_host.counters(ws, dev)
-        heavy = count > c1["heavy_t"]                  # the threshold in force: --heavy-threshold or min(256 + 64 * views per call, 1024)
+        heavy = count > c1["heavy_t"]                  # the threshold in force: --heavy-threshold or min(256 + 64 * views per call, 2048)
         heavy_px += int(count[heavy].sum().item())
         bytes_call = ph * C * esize + nt * C * 4 * 2 + len(calls[ci][1]) * H * W * 4 + n_rows * 4 * 2
         gather_bytes += bytes_call
@@ -831,11 +838,28 @@ def main():
         reduce_partials(dist, scratch, dst=dst)
         torch.cuda.synchronize(dev)
         del scratch
+    calibration = None
+    if dist is not None and h_rows > 0 and arm_arg == "auto":
+        # Which arm is faster depends on the links, the backend and the rank count (gloo rehearsals on one GPU: split 160 vs whole
+        # 171 ms at 2 ranks, 2117 vs 353 ms at 4) and no 8-GPU node was ever available to measure it: the timed arm is chosen from
+        # a short untimed calibration of both -- 2 steps each, bracketed like the timed region, MAX over ranks (so that every rank
+        # picks the same arm).  Both arms still run and are reported.
+        calibration = {}
+        for arm_split in (True, False):
+            step_dist(arm_split)                                   # one step to settle (RCCL sizes its channels by message size)
+            barrier()
+            t_c = time.perf_counter()
+            for _ in range(2):
+                step_dist(arm_split)
+            barrier()
+            calibration["split" if arm_split else "whole"] = round(_max_over_ranks(dist, time.perf_counter() - t_c, dev) / 2 * 1e3, 3)
+        default_split = calibration["split"] <= calibration["whole"]
     for _ in range(a.warmup):
         step()
     barrier()
     voxproj_host.profile_enable(True)
     state["exposed_s"] = 0.0
+    state["proj_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -845,6 +869,7 @@ def main():
     prof = voxproj_host.profile_read()
     voxproj_host.profile_enable(False)
     exposed_ms = state["exposed_s"] / max(1, a.steps) * 1e3
+    proj_ms = state["proj_s"] / max(1, a.steps) * 1e3
     reduced = {}      # checksums of the scene for the line (compared across runs by tests/test_gpu_bench_contract.py)
     verify = not os.environ.get("VOXPROJ_BENCH_NOVERIFY")
     if dist is None and verify:
@@ -890,6 +915,10 @@ def main():
     if dist is not None:
         if verify:
             reduced = verify_reduced()
+        # per-rank projection and exposed-collective time of the timed arm: min and max over the ranks show a straggler
+        per_rank = torch.zeros(world, 2, dtype=torch.float64, device=dev)
+        per_rank[rank] = torch.tensor([proj_ms, exposed_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(per_rank)
         t = torch.tensor([dt, exposed_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, exposed_ms = float(t[0].item()), float(t[1].item())
@@ -959,6 +988,12 @@ def main():
                                "collective_ms_exposed": round(exposed_ms, 3),
                                "projection_ms_per_step": round(ms_step - exposed_ms, 3),
                                "timed_arm": "split" if split else "whole", "arms": arms,
+                               "timed_arm_chosen_by": ("calibration" if calibration is not None else "--collective-arm " + arm_arg),
+                               "calibration": calibration,
+                               "collectives_per_pass": ("feature sums in two pieces + one int32 tensor {pixel counts, view counts, views seen}"
+                                                        if split else "feature sums + one int32 tensor {pixel counts, view counts, views seen}"),
+                               "per_rank": {"projection_ms": {"min": round(float(per_rank[:, 0].min().item()), 3), "max": round(float(per_rank[:, 0].max().item()), 3)},
+                                            "collective_ms_exposed": {"min": round(float(per_rank[:, 1].min().item()), 3), "max": round(float(per_rank[:, 1].max().item()), 3)}},
                                "split": ({"rows_reduced_under_the_last_gather": h_rows, "of": n_rows} if split else None),
                                "note": "max over ranks; the headline value includes the collective (no overlap between passes); "
                                        "collective_ms_exposed = pass - (zeroing + projection), the latter from HIP events.  split: the "

@@ -290,11 +290,11 @@ int vp_workspace_release(void *workspace);
  *   VP_OPT_HEAVY_THRESHOLD  voxels that collect more than this many pixels in ONE call are not summed by a single wavefront: they
  *                           are cut into parts of VP_OPT_PART_PIXELS pixels, each part summed by a wavefront of the same gather
  *                           launch, the partial rows added to the voxel's row in a fixed order by a follow-up kernel (calls of
- *                           ONE view: shared by the four wavefronts of a workgroup).  Default min(256 + 64*B*V, 1024) -- the
+ *                           ONE view: shared by the four wavefronts of a workgroup).  Default min(256 + 64*B*V, 2048) -- the
  *                           longest job a wavefront can get bounds the tail of the launch --, 320 for calls of one view;
  *                           VP_FLAG_SERIAL_SUMS overrides it with "never".  Never below the part size
  *   VP_OPT_PART_PIXELS      pixels per part of a split voxel (default: the threshold); raised to 2*B*V*H*W / slots when the call
- *                           is so large that its parts could outnumber the workspace's part slots (65536, fewer for rows wider
+ *                           is so large that its parts could outnumber the workspace's part slots (32768, fewer for rows wider
  *                           than 2 KiB)
  *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
  *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a

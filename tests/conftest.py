@@ -23,7 +23,7 @@ def oracle_mod():
 
 @pytest.fixture
 def heavy_threshold():
-    """Setter for VP_OPT_HEAVY_THRESHOLD on every workspace of both fronts (None = the library's default, min(256 + 64*B*V, 1024));
+    """Setter for VP_OPT_HEAVY_THRESHOLD on every workspace of both fronts (None = the library's default, min(256 + 64*B*V, 2048));
     the default is restored afterwards.  Replaces the environment variable of ABI v2: options belong to the workspace."""
     import voxproj_host
 

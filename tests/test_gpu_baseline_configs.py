@@ -1,5 +1,5 @@
 """GPU parity at the BASELINE.json configurations' OWN shapes, with the library's production settings
-(no heavy-threshold override: voxels above min(256 + 64*B*V, 1024) pixels per call are summed in parts).
+(no heavy-threshold override: voxels above min(256 + 64*B*V, 2048) pixels per call are summed in parts).
 
   config 2  R1  ~80k voxels, 484x274x512 feature maps          -> 4 views in one call vs the oracle
   config 3  R2  200k voxels, 968x548x512 feature maps          -> 8 views in ONE call vs the oracle
@@ -73,7 +73,7 @@ def _feature_config(oracle_mod, n_vox, n_views_scene, W, H, C, views, min_heavy)
     ctr = voxproj_host.counters(ws, dev)
     assert ctr["bad_id"] == 0 and ctr["box_miss"] == 0
     heavy_t = ctr["heavy_t"]
-    assert heavy_t == min(256 + 64 * 1 * V, 1024)           # voxproj.hip: the production threshold
+    assert heavy_t == min(256 + 64 * 1 * V, 2048)           # voxproj.hip: the production threshold
     heavy = count > heavy_t
     assert ctr["n_heavy"] == int(heavy.sum()) >= min_heavy, (ctr, int(heavy.sum()))
     got = out_t.cpu().numpy()
@@ -133,7 +133,7 @@ def test_config5_rgb_500k_voxels_eight_views_vs_oracle(oracle_mod):
 
 def test_config3_full_300_view_pipelined_pass_counts_vs_oracle(oracle_mod):
     # The WHOLE metric workload the way bench.py drives it -- 300 views cut into calls by bench.plan_calls itself (today:
-    # five pipelined calls of 60 views, 65 GB of maps resident, heavy threshold min(256 + 64 * 60, 1024) pixels), production
+    # five pipelined calls of 60 views, 65 GB of maps resident, heavy threshold min(256 + 64 * 60, 2048) pixels), production
     # heavy-voxel threshold, the resident pool cycled -- against the oracle's ray-march of all 300 views: per-voxel pixel
     # counts and per-voxel view counts bit-exact.  The feature sums (326 GB of rows) cannot be replayed on the host; they
     # are checked through a checksum of checksums: per channel, the sum over all voxel rows must equal the sum of the
@@ -247,7 +247,7 @@ def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
     got_c = count_t.cpu().numpy().astype(np.int64)
     assert np.array_equal(got_c, count_ref) and np.array_equal(views_t.cpu().numpy().astype(np.int64), views_ref)
     heavy_t = ctr["heavy_t"]
-    assert heavy_t == 1024                                               # voxproj.hip: min(256 + 64 * B * V, 1024)
+    assert heavy_t == 2048                                               # voxproj.hip: min(256 + 64 * B * V, 2048)
     heavy = torch.from_numpy(count_ref > heavy_t).to(dev)
     assert ctr["n_heavy"] == int(heavy.sum().item()) > 0 and int(count_ref.max()) > heavy_t
     ref[0] = 0

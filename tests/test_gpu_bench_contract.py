@@ -42,26 +42,39 @@ def _no_launcher_env():
     return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
 
 
-def test_bench_two_ranks_gloo_rehearsal_started_by_bench_itself():
-    """`python bench.py --gpus 2` with NO launcher: the parent starts the two ranks as a child torchrun before touching the GPU
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_gloo_rehearsal_started_by_bench_itself(ranks):
+    """`python bench.py --gpus N` with NO launcher: the parent starts the N ranks as a child torchrun before touching the GPU
     and relays rank 0's line.  gloo + --single-device rehearse the multi-rank step on the one GPU of the box: the step runs
-    through VoxelFeatureAggregator.add_views / add_final_views, both collective arms are in the line."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "S0", "--steps", "2", "--warmup", "1",
-                        "--dist-backend", "gloo", "--single-device"], capture_output=True, text=True, timeout=600, env=_no_launcher_env())
+    through VoxelFeatureAggregator.add_views / add_final_views; the TIMED collective arm is the one a short untimed calibration
+    of both arms found faster (round 5: no arm is the default by guess), both arms are in the line, the integers travel in one
+    tensor, and the line shows the ranks' spread."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--workload", "S0", "--steps", "2", "--warmup", "1",
+                        "--dist-backend", "gloo", "--single-device"], capture_output=True, text=True, timeout=900, env=_no_launcher_env())
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong" and "cpu_baseline" not in d
     # north_star's collective is the default, named in the line; the headline pays it inside the pass
-    assert "all-reduce" in d["config"]["parallelism"] and d["collective"]["op"] == "all-reduce"
-    assert 0 < d["collective"]["collective_ms_exposed"] < d["ms_per_step"]
+    c = d["collective"]
+    assert "all-reduce" in d["config"]["parallelism"] and c["op"] == "all-reduce"
+    assert 0 < c["collective_ms_exposed"] < d["ms_per_step"]
     assert d["hit_pixels_per_step"] > 0 and d["value"] > 0 and d["reduced_hit_pixels"] > 0
-    # the pass's last call is cut into two row ranges; the first half's rows are reduced under the second half's gather
-    sp = d["collective"]["split"]
-    assert 0 < sp["rows_reduced_under_the_last_gather"] < sp["of"] == 10001
-    arms = d["collective"]["arms"]
-    assert d["collective"]["timed_arm"] == "split" and set(arms) == {"split", "whole"}
-    assert arms["split"]["ms_per_step"] == d["ms_per_step"] and arms["whole"]["ms_per_step"] > 0
-    assert "VoxelFeatureAggregator" in d["collective"]["through"]
+    arms, cal, timed = c["arms"], c["calibration"], c["timed_arm"]
+    assert set(arms) == {"split", "whole"} == set(cal) and c["timed_arm_chosen_by"] == "calibration"
+    assert timed == min(cal, key=cal.get), (timed, cal)               # the faster arm of the calibration is the timed one
+    other = "whole" if timed == "split" else "split"
+    assert arms[timed]["ms_per_step"] == d["ms_per_step"] and arms[other]["ms_per_step"] > 0
+    assert arms[timed]["ms_per_step"] <= 1.25 * arms[other]["ms_per_step"], arms      # ... and it is not the slower one by far
+    if timed == "split":
+        # the pass's last call is cut into two row ranges; the first half's rows are reduced under the second half's gather
+        assert 0 < c["split"]["rows_reduced_under_the_last_gather"] < c["split"]["of"] == 10001
+    else:
+        assert c["split"] is None
+    assert "one int32 tensor" in c["collectives_per_pass"]
+    pr = c["per_rank"]
+    assert 0 < pr["projection_ms"]["min"] <= pr["projection_ms"]["max"] < d["ms_per_step"]
+    assert pr["collective_ms_exposed"]["min"] <= pr["collective_ms_exposed"]["max"] == c["collective_ms_exposed"]
+    assert "VoxelFeatureAggregator" in c["through"]
 
 
 def test_bench_refuses_more_ranks_than_gpus():
@@ -193,6 +206,7 @@ def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["collective"]["backend"] == "nccl" and d["collective"]["op"] == "all-reduce"
     assert d["collective"]["collective_ms_exposed"] >= 0 and set(d["collective"]["arms"]) == {"split", "whole"}
+    assert d["collective"]["timed_arm"] == min(d["collective"]["calibration"], key=d["collective"]["calibration"].get)
     assert d["reduced_hit_pixels"] == d["hit_pixels_per_step"]
     assert "rehearsal" in d["config"]["parallelism"] and "cpu_baseline" not in d
     assert _overlapped(d), (d["ms_per_step"], d["phase_ms_per_step"])

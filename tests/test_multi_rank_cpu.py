@@ -79,9 +79,31 @@ def _worker(rank, world, port, out_path):
     mine = views_of_rank(s.n_views, rank, world)
     assert mine == list(range(rank, 7, world))
     res = {}
+    # every collective the aggregator issues, by op and element count (round 5: the integers travel in ONE tensor)
+    issued = []
+    real_all_reduce, real_reduce = dist.all_reduce, dist.reduce
+
+    def counting_all_reduce(t, *a, **k):
+        issued.append(("all_reduce", str(t.dtype), t.numel()))
+        return real_all_reduce(t, *a, **k)
+
+    def counting_reduce(t, *a, **k):
+        issued.append(("reduce", str(t.dtype), t.numel()))
+        return real_reduce(t, *a, **k)
+
+    dist.all_reduce, dist.reduce = counting_all_reduce, counting_reduce
+    n_rows = s.n_vox + 1
+    n_ints = 2 * ((n_rows + 63) & ~63) + 64
     for name, dst in (("all", None), ("root", 0)):
         agg = _filled_aggregator(oracle, s, feats, mine)
+        assert agg.count.data_ptr() == agg._ints.data_ptr() and agg._ints.numel() == n_ints      # views into the one tensor
+        del issued[:]
         agg.all_reduce(dst=dst)                                # the entry point's own combination step
+        if dst is None:                                        # the sums + ONE integer tensor {pixel counts, view counts, views seen}
+            assert issued == [("all_reduce", "torch.float32", n_rows * 8), ("all_reduce", "torch.int32", n_ints)], issued
+        else:                                                  # reduce to the root, then the root's view total to everyone
+            assert issued == [("reduce", "torch.float32", n_rows * 8), ("reduce", "torch.int32", n_ints),
+                              ("all_reduce", "torch.int32", 1)], issued
         assert agg.n_seen == 7
         if rank == 0 or dst is None:
             r = agg.result()
@@ -96,9 +118,14 @@ def _worker(rank, world, port, out_path):
         agg = _filled_aggregator(oracle, s, feats, mine[:-2])
         log = []
         _final_call_stand_in(oracle, agg, s, feats, log)
+        del issued[:]
         h = agg.add_final_views(torch.tensor(mine[-2:]), torch.zeros(2, 4, 4), torch.zeros(4), dst=None, split=split)
-        n_rows = s.n_vox + 1
         assert h == (split_point(n_rows) if split else 0) and 0 <= h < n_rows and h % 64 == 0
+        if split:                                              # the sums in two pieces (the first under the second gather) + the integers
+            assert issued == [("all_reduce", "torch.float32", h * 8), ("all_reduce", "torch.float32", (n_rows - h) * 8),
+                              ("all_reduce", "torch.int32", n_ints)], issued
+        else:
+            assert issued == [("all_reduce", "torch.float32", n_rows * 8), ("all_reduce", "torch.int32", n_ints)], issued
         assert log == ([(False, 0, h), (True, h, n_rows)] if split else [(False, 0, n_rows)]), log
         assert vh.VP_OPT_ROW_BEGIN not in agg.ws.options and vh.VP_OPT_ROW_END not in agg.ws.options     # range reset
         assert agg.n_seen == 7

@@ -54,7 +54,7 @@ def test_trajectory_views_are_a_smooth_path_and_the_scene_is_exact(oracle_mod):
         chunk, n_calls, _ = bm.plan_calls(n_views, H, W, C, 4)
         first = np.bincount(hits[0, :chunk].reshape(-1), minlength=n_vox + 1)[1:]
         assert first.max() * 16 >= 100000, first.max() * 16           # a voxel with >= 10^5 full-resolution pixels in the first call
-        heavy_t = min(256 + 64 * chunk, 1024) / 16.0
+        heavy_t = min(256 + 64 * chunk, 2048) / 16.0
         assert first[first > heavy_t].sum() > 0.9 * first.sum()       # the close-up call: nearly every pixel in a heavy voxel
         # clutter: about half of the occupied cells are not on the room's shell
         nz, ny, nx = s.occ.shape

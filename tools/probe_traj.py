@@ -3,7 +3,8 @@ feature-pool allocation (its placement moves the gather by several per cent, so 
   python tools/probe_traj.py [--workload R2T|A1|R2] [--calls 0,1,2] [--rounds 3] ARM [ARM ...]
   ARM = path/to/lib.so[:heavy=N][:part=N]     (heavy / part: VP_OPT_HEAVY_THRESHOLD / VP_OPT_PART_PIXELS of the workspace)
 Prints, per call and arm, the mean k_gather time per launch (HIP events of the library), the fraction of 8 TB/s on the call's
-algorithmic bytes, and the number of parts."""
+algorithmic bytes, and the number of parts.  --pipeline: also the WHOLE pass of the leg per arm, its calls pipelined
+(VP_FLAG_PIPELINE) as bench.py issues them, wall time per pass."""
 import importlib.util
 import os
 import sys
@@ -76,7 +77,34 @@ for rnd in range(rounds):
             info[(ci, arm)] = (ph * C * 4 + nt * C * 4 * 2 + len(views) * H * W * 4 + (n_vox + 1) * 8, ctr["n_parts"], ctr["n_heavy"], ctr["heavy_t"],
                                float(out.double().sum().item()))
         voxproj_host.profile_enable(False)
+        if "--pipeline" in sys.argv:
+            import time
+            all_calls = [list(range(ci * V, min(n_views, (ci + 1) * V))) for ci in range(n_calls)]
+            vmis = [c2w[v].reshape(-1).contiguous() for v in all_calls]
+            torch.cuda.synchronize(dev)
+            for rep in range(4):
+                out.zero_(); count.zero_()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                if rep == 3:
+                    voxproj_host.profile_enable(True)
+                for ci, views in enumerate(all_calls):
+                    voxproj_host.project_features_raw(feats[:, :len(views)], occ, vmis[ci], intr, opts, count, out, origin, s.voxel_size,
+                                                      workspace=ws, sync=False, pipeline=True, reuse_accel=True)
+                voxproj_host.workspace_status(ws, dev)
+                torch.cuda.synchronize(dev)
+                if rep > 0:
+                    res.setdefault(("pass", arm), []).append((time.perf_counter() - t0) * 1e3)
+            p = voxproj_host.profile_read()
+            voxproj_host.profile_enable(False)
+            info[("pass", arm)] = (p["gather_ms"], p["first_hit_ms"], p["heavy_ms"])
         ws.release()
+if "--pipeline" in sys.argv:
+    for arm in arms:
+        t = np.array(res[("pass", arm)])
+        g = info[("pass", arm)]
+        print(f"pass    {os.path.basename(arm):44s} {t.mean():8.3f} ms per pipelined pass (min {t.min():8.3f}, {len(t)} passes)  "
+              f"gather {g[0]:7.3f}  march {g[1]:7.3f}  combine {g[2]:6.3f}  -> {n_vox * n_views / (t.mean() * 1e-3) / 1e6:8.1f} Mvoxel-views/s")
 print(f"# {name}: {V} views per call, calls {call_ids}, {rounds} rounds x 2 timed launches per arm, every call alone on the device")
 for ci in call_ids:
     for arm in arms:
