@@ -312,6 +312,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     if (gather_only) { heavy_t = st->last_heavy_t; part_px = st->last_part_px; }   // the thresholds of the call whose march is reused
 #ifdef VP_DIAG
     if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
+    if (flags & VP_FLAG_DIAG_WAVES) heavy_t = -2;      // ... per-wavefront clock stamps
 #endif
     const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
     int4 *parts = (int4 *)(ws + l.parts[q]), *split = (int4 *)(ws + l.split[q]), *pmeta = (int4 *)(ws + l.pmeta[q]);

@@ -241,7 +241,8 @@ enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_ZERO = 3 /* never written
        ST_STICKY_STALE = 61, ST_STICKY_BADID = 62, ST_STICKY_STUCK = 63, ST_WORDS = 64 };
 constexpr unsigned WS_MAGIC = 0x56585033u;   // "VXP3"
 #ifdef VP_DIAG
-enum { VP_FLAG_DIAG_EVALS = 1 << 20 };      // diagnostic build only (make diag): the hit image receives per-ray evaluation counts
+enum { VP_FLAG_DIAG_EVALS = 1 << 20,       // diagnostic build only (make diag): the hit image receives per-ray evaluation counts
+       VP_FLAG_DIAG_WAVES = 1 << 21 };     // ... per-wavefront clock stamps and iteration counts (tools/march_waves.py)
 #endif
 
 // key of the tables a workspace holds: shape they were built for + how many times this record has built them

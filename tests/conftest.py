@@ -37,3 +37,23 @@ def heavy_threshold():
             pass
     yield set_
     set_(None)
+
+
+@pytest.fixture
+def workspace_option():
+    """Setter for any VP_OPT_* on every workspace of both fronts (None = the library's default); restored afterwards."""
+    import voxproj_host
+    touched = set()
+
+    def set_(option, value):
+        touched.add(int(option))
+        voxproj_host.set_default_option(int(option), value)
+        try:
+            import torch  # noqa: F401
+            import project_features_cuda as m
+            m.set_workspace_option(int(option), -1 if value is None else int(value))
+        except ImportError:
+            pass
+    yield set_
+    for opt in touched:
+        set_(opt, None)

@@ -1,6 +1,7 @@
 """One-off stress of the projector against the CPU oracle: N random configurations (grid, poses inside / outside / next to
 voxels, intrinsics, ray range and increment, channels, views per call, fp32 / fp16 maps, plain / pipelined call sequences,
-heavy thresholds from 3 pixels to none, calls cut into voxel-ID ranges, one-view calls through the one-view kernel with its
+heavy thresholds from 3 pixels to none, split voxels in parts of 1 pixel upwards,
+calls cut into voxel-ID ranges, one-view calls through the one-view kernel with its
 default grid, with grids of one and three workgroups, and through the general kernel).  IDs, counts and view counts must be exact, sums within 1e-4 of the oracle's
 float64 accumulation (bit-identical where no heavy path can be involved).  python tools/stress_differential.py [N] [seed]"""
 import os
@@ -56,6 +57,7 @@ for case in range(N):
     ws = voxproj_host.Workspace(); keep = []
     ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, ht or None)
     ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, [None, None, 1001, 1003, 0][int(rng.integers(0, 5))])
+    ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, [None, None, 1, 2, 5, 40][int(rng.integers(0, 6))])       # parts of split voxels
     for call in range(int(rng.integers(1, 4))):
         V = int(rng.choice([1, 1, 1, 2, 3, 7, 8, 9, 20, 66]))
         c2w = np.zeros((B, V, 4, 4), np.float32)
