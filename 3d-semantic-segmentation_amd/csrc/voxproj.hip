@@ -397,7 +397,10 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         const long long want = rec.opt_one_view >= 1000 ? rec.opt_one_view - 1000 : (long long)device_cus() * per_cu;
         const long long cap = (n_rows - 1 + 3) / 4;           // never more wavefronts than voxel IDs
         const unsigned nblk = (unsigned)std::max<long long>(1, std::min(want, cap));
-        g.heavy_blocks = heavy_t != 2147483647 ? (int)std::min<unsigned>(HEAVY_BLOCKS, nblk) : 0;
+        // every workgroup of the grid takes heavy voxels first (round 5; rounds 1-4: the first 128): on a close-up frame EVERY
+        // voxel of the view is heavy -- 300-400 of them -- and 128 workgroups summed them three apiece while the rest of the grid
+        // had nothing to deal (0.70 ms per call instead of 0.3, profiles/r05_dropin_trajectory.log)
+        g.heavy_blocks = heavy_t != 2147483647 ? (int)nblk : 0;
         if (n_rows > 1) VP_DISPATCH_GATHER_ONE((long long)H * W <= GATHER_G32_SMALL_IMAGE, vec_ok, C, dim3(nblk), dim3(256), 0, s0, g, p);
         sp.end();
     } else if (n_rows > 1) {

@@ -20,6 +20,10 @@ namespace {
 // float32 (DPC:70,75), built in LDS by the workgroup: three correctly-rounded float64 divisions fewer per voxel-view.
 // ------------------------------------------------------------------------------------------------
 enum { CST_BADID = 0, CST_DUP = 1 };
+#ifndef COLOR_UNROLL
+#define COLOR_UNROLL 1     // views whose pixel gathers are in flight together per lane of k_project_colors
+#endif
+constexpr int COLOR_CHUNK = 64;   // views whose pose and intrinsics are staged in LDS together
 
 __global__ __launch_bounds__(256) void k_color_cells(const int *__restrict__ occ, long long cells, int *cell_of_id,
                                                      long long n_rows, int *status)
@@ -33,7 +37,7 @@ __global__ __launch_bounds__(256) void k_color_cells(const int *__restrict__ occ
     }
 }
 
-__global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ cell_of_id, int dimy, int dimx,
+__global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict__ cell_of_id, int dimy, int dimx,
                                                         const float *__restrict__ c2w, const float *__restrict__ intr,
                                                         int V, float ox, float oy, float oz, double vs,
                                                         const unsigned char *__restrict__ img, int img_h, int img_w,
@@ -41,52 +45,101 @@ __global__ __launch_bounds__(256) void k_project_colors(const int *__restrict__ 
                                                         int *pixel_uv, long long n_rows, int view_base)
 {
     __shared__ float lut[256];
+    // pose and intrinsics of COLOR_CHUNK views at a time, widened to float64 once per workgroup: per view R^T row by row
+    // (m0 m4 m8 | m1 m5 m9 | m2 m6 m10), the camera position (m3 m7 m11), fx fy cx cy.  Read as LDS broadcasts; fetched
+    // through the scalar unit one element at a time where it was needed -- six dependent scalar-load round trips per view and
+    // wavefront -- the kernel spent 55 % of its wave cycles parked (profiles/r05_r4_counters.txt).
+    __shared__ double cam[COLOR_CHUNK][16];
     lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);                                                    // DPC:70,75
-    __syncthreads();
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_rows) return;
-    const int cell = id > 0 ? cell_of_id[id] : -1;        // row 0 is the dummy of the 1-based IDs
-    if (cell < 0) {
+    bool live = id < n_rows;
+    const int cell = (live && id > 0) ? cell_of_id[id] : -1;        // row 0 is the dummy of the 1-based IDs
+    if (live && cell < 0) {
         if (pixel_uv)
             for (int v = 0; v < V; v++) {
                 pixel_uv[((long long)v * n_rows + id) * 2 + 0] = -1;
                 pixel_uv[((long long)v * n_rows + id) * 2 + 1] = -1;
             }
-        return;
+        live = false;
     }
-    const int z = cell / (dimy * dimx);
-    const int r = cell - z * (dimy * dimx);
+    const int z = live ? cell / (dimy * dimx) : 0;
+    const int r = live ? cell - z * (dimy * dimx) : 0;
     const int y = r / dimx, x = r - y * dimx;
     const double wx = (double)ox + vs * (double)x, wy = (double)oy + vs * (double)y, wz = (double)oz + vs * (double)z;   // DPC:60
-    float sr = color_sum[id * 3 + 0], sg = color_sum[id * 3 + 1], sb = color_sum[id * 3 + 2];
-    int hc = hit_count[id];
-    int fv = first_view ? first_view[id] : 0;
-    for (int v = 0; v < V; v++) {
-        const float *m = c2w + (long long)v * 16;
-        const double dx = wx - (double)m[3], dy = wy - (double)m[7], dz = wz - (double)m[11];                  // DPC:61-63
-        const double cx = (double)m[0] * dx + (double)m[4] * dy + (double)m[8] * dz;                            // R^T d
-        const double cy = (double)m[1] * dx + (double)m[5] * dy + (double)m[9] * dz;
-        const double cz = (double)m[2] * dx + (double)m[6] * dy + (double)m[10] * dz;
-        int ui = -1, vi = -1;
-        if (cz > 0.0) {                                                                                         // DPC:65
-            const double u = (double)intr[v * 4 + 0] * (cx / cz) + (double)intr[v * 4 + 2];                     // DPC:66-67
-            const double w = (double)intr[v * 4 + 1] * (cy / cz) + (double)intr[v * 4 + 3];
-            const double ur = rint(u), vr = rint(w);                                                            // DPC:68 (half to even)
-            if (ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h) {                          // DPC:69
-                ui = (int)ur; vi = (int)vr;
-                const unsigned char *px = img + (((long long)v * img_h + vi) * img_w + ui) * 3;
-                sr += lut[px[0]];                                                                               // AGGC:139
-                sg += lut[px[1]];
-                sb += lut[px[2]];
-                hc += 1;                                                                                        // AGGC:140
-                fv = min(fv, view_base + v);
+    float sr = 0.f, sg = 0.f, sb = 0.f;
+    int hc = 0, fv = 0;
+    if (live) {
+        sr = color_sum[id * 3 + 0]; sg = color_sum[id * 3 + 1]; sb = color_sum[id * 3 + 2];
+        hc = hit_count[id];
+        fv = first_view ? first_view[id] : 0;
+    }
+    for (int vc = 0; vc < V; vc += COLOR_CHUNK) {
+        __syncthreads();      // the table and the previous chunk are no longer being read
+        for (int i = threadIdx.x; i < COLOR_CHUNK * 16; i += 256) {
+            const int v = vc + (i >> 4), k = i & 15;
+            if (v < V) {
+                // k = 0..8: R^T (column c of c2w's rotation as row c), 9..11: position, 12..15: intrinsics
+                const int src = k < 9 ? (k % 3) * 4 + k / 3 : (k - 9) * 4 + 3;
+                cam[i >> 4][k] = k < 12 ? (double)c2w[(long long)v * 16 + src] : (double)intr[v * 4 + (k - 12)];
             }
         }
-        if (pixel_uv) {
-            pixel_uv[((long long)v * n_rows + id) * 2 + 0] = ui;
-            pixel_uv[((long long)v * n_rows + id) * 2 + 1] = vi;
+        __syncthreads();
+        if (!live) continue;
+        const int nv = min(COLOR_CHUNK, V - vc);
+        // Views are taken COLOR_UNROLL at a time: the pixel addresses of the group are computed first, their loads go out
+        // together, and the colours are added afterwards in view order (the float32 sums are the same bits as one view at a time).
+        for (int v0 = 0; v0 < nv; v0 += COLOR_UNROLL) {
+            int ui[COLOR_UNROLL], vi[COLOR_UNROLL];
+#pragma unroll
+            for (int j = 0; j < COLOR_UNROLL; j++) {
+                ui[j] = -1; vi[j] = -1;
+                if (v0 + j < nv) {
+                    const double *m = cam[v0 + j];
+                    const double dx = wx - m[9], dy = wy - m[10], dz = wz - m[11];                                  // DPC:61-63
+                    const double cx = m[0] * dx + m[1] * dy + m[2] * dz;                                            // R^T d
+                    const double cy = m[3] * dx + m[4] * dy + m[5] * dz;
+                    const double cz = m[6] * dx + m[7] * dy + m[8] * dz;
+                    if (cz > 0.0) {                                                                                 // DPC:65
+                        const double u = m[12] * (cx / cz) + m[14];                                                 // DPC:66-67
+                        const double w = m[13] * (cy / cz) + m[15];
+                        const double ur = rint(u), vr = rint(w);                                                    // DPC:68 (half to even)
+                        if (ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h) {                  // DPC:69
+                            ui[j] = (int)ur; vi[j] = (int)vr;
+                        }
+                    }
+                }
+            }
+            // the pixel's three bytes with ONE load (an unaligned dword; the fourth byte belongs to the next pixel and is
+            // dropped): 64 lanes x 3 byte loads to 64 different cache lines kept the CU's one address unit busy longer than
+            // the arithmetic took.  The last pixel of an image is read byte by byte (nothing may lie behind it).
+            unsigned pix[COLOR_UNROLL];
+#pragma unroll
+            for (int j = 0; j < COLOR_UNROLL; j++) {
+                pix[j] = 0u;
+                if (ui[j] >= 0) {
+                    const unsigned char *px = img + (((long long)(vc + v0 + j) * img_h + vi[j]) * img_w + ui[j]) * 3;
+                    if (ui[j] == img_w - 1 && vi[j] == img_h - 1) pix[j] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+                    else __builtin_memcpy(&pix[j], px, 4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < COLOR_UNROLL; j++) {
+                const int v = vc + v0 + j;
+                if (ui[j] >= 0) {
+                    sr += lut[pix[j] & 255u];                                                                       // AGGC:139
+                    sg += lut[(pix[j] >> 8) & 255u];
+                    sb += lut[(pix[j] >> 16) & 255u];
+                    hc += 1;                                                                                        // AGGC:140
+                    fv = min(fv, view_base + v);
+                }
+                if (pixel_uv && v0 + j < nv) {
+                    pixel_uv[((long long)v * n_rows + id) * 2 + 0] = ui[j];
+                    pixel_uv[((long long)v * n_rows + id) * 2 + 1] = vi[j];
+                }
+            }
         }
     }
+    if (!live) return;
     color_sum[id * 3 + 0] = sr; color_sum[id * 3 + 1] = sg; color_sum[id * 3 + 2] = sb;
     hit_count[id] = hc;
     if (first_view) first_view[id] = fv;

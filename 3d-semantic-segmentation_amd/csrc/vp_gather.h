@@ -918,6 +918,9 @@ template <int K, int VEC, int U>
 __global__ __launch_bounds__(256) void k_gather_one(GatherArgs g, Params p)
 {
     __builtin_amdgcn_s_setprio(3);
+    // rows in flight per wavefront of the heavy role: 8 (the deal's wavefronts: U) -- a close-up frame is ALL heavy voxels, a few
+    // hundred workgroups of four wavefronts each: with 4 rows of 2 KiB per wavefront too few bytes are in flight to fill HBM
+    constexpr int UH = (VEC == 4 && U < 8) ? 8 : U;
     __shared__ __attribute__((aligned(16))) float part[GW_MERGED][64 * K * VEC];
     __shared__ int part_found[GW_MERGED];
     if ((int)blockIdx.x < g.heavy_blocks) {
@@ -926,9 +929,9 @@ __global__ __launch_bounds__(256) void k_gather_one(GatherArgs g, Params p)
             const int id = g.heavy_list[h];
             if (id < g.row_lo || id >= g.row_hi) continue;
             const int expected = g.cnt_call[id];
-            if (!gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, false)) {
+            if (!gather_voxel_block<K, VEC, UH, GW_MERGED>(g, p, id, expected, part, part_found, false)) {
                 if (threadIdx.x == 0) atomicAdd(&g.status[ST_BOXMISS], 1);
-                gather_voxel_block<K, VEC, U, GW_MERGED>(g, p, id, expected, part, part_found, true);
+                gather_voxel_block<K, VEC, UH, GW_MERGED>(g, p, id, expected, part, part_found, true);
             }
         }
     }

@@ -160,7 +160,7 @@ def parse():
     return a
 
 
-PMC_PROFILE = "r04_pmc_traffic.json"           # the round's committed counter passes (tools/profile_round.sh writes it)
+PMC_PROFILE = "r05_pmc_traffic.json"           # the round's committed counter passes (tools/profile_round.sh writes it)
 
 
 def source_digest():
@@ -197,7 +197,7 @@ def pmc_traffic(workload, chunk, dtype):
 
 
 PMC_RUNS = {   # key: (directory suffix of tools/profile_round.sh, views per launch of that pass = plan_calls' default for the leg)
-    "R2_f32": ("f32", 60), "R2_f16": ("f16", 100), "R1_f32": ("R1", 50)}
+    "R2_f32": ("f32", 60), "R2_f16": ("f16", 100), "R1_f32": ("R1", 50), "R2T_f32": ("R2T", 60), "A1_f32": ("A1", 54)}
 
 
 def write_pmc_json(prof_dir, out_path):
@@ -225,8 +225,9 @@ def write_pmc_json(prof_dir, out_path):
                                   "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"])), 1)}
                               for k, v in per.items() if v.get("FETCH_SIZE") and v.get("WRITE_SIZE")})
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --views 120 --chunk 60 | --views 200 --chunk 100 --dtype f16 | --workload R1, MI355X "
-                     "(tools/profile_round.sh)",
+                     "--no-cpu-baseline --views 120 --chunk 60 | --views 200 --chunk 100 --dtype f16 | --workload R1 | --workload R2T | "
+                     "--workload A1, MI355X (tools/profile_round.sh); the trajectory legs' launches differ (close-ups, misses): their "
+                     "figures are means over the launches of one pass",
            "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane streaming reads -> doubled by the reader "
                    "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; units KB",
            "source_digest": source_digest(), "runs": runs}
@@ -266,6 +267,45 @@ def cpu_baseline(scene, C, n_views, n_threads):
                 sample=f"{n_views} of the workload's views at full resolution, all {scene.n_vox} voxels, "
                        f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices; {os.cpu_count()} logical CPUs "
                        f"visible, {n_threads} granted to this process)")
+
+
+def colour_projection_torch_cpu(occ_zyx, c2w, intr4, grid_origin, voxel_size, img):
+    """The reference's colour loop (debug_project_colors.py:58-73: every occupied voxel centre through the pinhole model in
+    numpy float64, in-front test, banker's rounding to the nearest pixel, image-bounds test, img[v, u] / 255) as one vectorised
+    torch-CPU expression.  Returns (colors f32 [n,3], zyx i64 [n,3], uv i64 [n,2]) in the loop's raster order."""
+    zyx = (occ_zyx > 0).nonzero(as_tuple=False)
+    world = grid_origin.to(torch.float64)[None, :] + float(voxel_size) * zyx[:, [2, 1, 0]].to(torch.float64)      # DPC:60
+    m = c2w.reshape(4, 4).to(torch.float64)
+    d = world - m[:3, 3][None, :]
+    cam = torch.stack([m[0, i] * d[:, 0] + m[1, i] * d[:, 1] + m[2, i] * d[:, 2] for i in range(3)], 1)            # R^T d, DPC:61-63
+    fx, fy, cx, cy = (intr4.reshape(-1)[i].to(torch.float64) for i in range(4))
+    front = cam[:, 2] > 0                                                                                         # DPC:65
+    z = torch.where(front, cam[:, 2], torch.ones_like(cam[:, 2]))
+    u = torch.round(fx * (cam[:, 0] / z) + cx)                                                                    # DPC:66-68 (half to even)
+    v = torch.round(fy * (cam[:, 1] / z) + cy)
+    ok = front & (u >= 0) & (u < img.shape[1]) & (v >= 0) & (v < img.shape[0])                                    # DPC:69
+    ui, vi = u[ok].long(), v[ok].long()
+    colors = (img[vi, ui].to(torch.float64) / 255.0).to(torch.float32)                                            # DPC:70,75
+    return colors, zyx[ok], torch.stack([ui, vi], 1)
+
+
+def cpu_colour_loop(scene, img_u8, n_views, n_threads):
+    """cpu_torch_loop of the R4 leg: colour_projection_torch_cpu over n_views views on the box's host cores."""
+    torch.set_num_threads(n_threads)
+    occ = torch.from_numpy(scene.occ)
+    c2w = torch.from_numpy(scene.c2w)
+    intr = torch.from_numpy(scene.intr)
+    origin = torch.from_numpy(np.asarray(scene.grid_origin, dtype=np.float32))
+    img = torch.from_numpy(img_u8)
+    colour_projection_torch_cpu(occ, c2w[0], intr, origin, scene.voxel_size, img)        # warm
+    t0 = time.perf_counter()
+    seen = 0
+    for v in range(n_views):
+        seen += colour_projection_torch_cpu(occ, c2w[v], intr, origin, scene.voxel_size, img)[0].shape[0]
+    dt = time.perf_counter() - t0
+    return dict(value=round(scene.n_vox * n_views / dt / 1e6, 3), unit="Mvoxel-views/s", cores=n_threads,
+                what="the reference's colour loop (debug_project_colors.py:58-73) as one vectorised float64 torch-CPU expression per view",
+                sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {seen} voxel-views in the image")
 
 
 def cpu_torch_loop(scene, n_views, n_threads):
@@ -405,6 +445,7 @@ def bench_colors(a, dev, rank, world, dist):
             res["cpu_baseline"] = dict(value=round(N * nv / dtc / 1e6, 3), unit="Mvoxel-views/s", cores=1, kind="port",
                                        sample=f"{nv} of the workload's views, all {N} voxels, {dtc:.1f} s wall "
                                               "(oracle_rgb_project: scalar C restatement of debug_project_colors.py:54-81)")
+            res["cpu_torch_loop"] = cpu_colour_loop(s, img_np, min(8, V), host_cores())
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -1013,13 +1054,14 @@ def main():
                          "level": (None if stream_gbs <= 0 else "fast" if ach / stream_gbs >= 0.98 else "mid" if ach / stream_gbs >= 0.93 else "slow"),
                          "traffic": (int(pmc_traffic(a.workload, chunk, a.dtype) * len(my_views) / len(calls))
                                      if (not a.views and world == 1 and pmc_traffic(a.workload, chunk, a.dtype)) else None),
-                         "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc passes of this build, rescaled to this "
+                         "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc passes of this build, rescaled to this "
                                            "run's views per launch; null when the kernel sources changed since) -- not measured in this run",
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }
         if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)
             ncores = host_cores()
             res["cpu_baseline"] = cpu_baseline(scene, C, min(a.cpu_views, n_views), ncores)
+            res["cpu_baseline_1t"] = cpu_baseline(scene, C, min(2, n_views), 1)          # the oracle single-threaded too
             res["cpu_torch_loop"] = cpu_torch_loop(scene, min(16, n_views), ncores)
         print(json.dumps(res), flush=True)
     if dist is not None:

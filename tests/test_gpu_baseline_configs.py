@@ -260,5 +260,5 @@ def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
     solid = touched[:, None] & (ref.abs() >= 1e-2 * row_mag)
     rel_el = err[solid] / ref.abs()[solid]
     assert float(rel_el.max().item()) <= 1e-4, float(rel_el.max().item())
-    # and the heavy rows on their own (the workgroup role's fixed summation tree)
+    # and the split rows on their own (parts combined in slot order)
     assert float((err[heavy] / row_mag[heavy]).max().item()) <= 1e-4

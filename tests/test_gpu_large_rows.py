@@ -51,7 +51,7 @@ def _check(count_t, out_t, ref_c, ref_o, bitwise=True):
 
 
 def test_drop_in_call_with_rows_past_4_gib(oracle_mod, heavy_threshold):
-    """Few views per call: the gather variant without the heavy role, heavy voxels by `k_gather_heavy` (threshold 6)."""
+    """Few views per call, heavy threshold 6: most voxels are summed in parts whose partial rows k_combine_parts adds up."""
     import voxproj_host
     heavy_threshold(6)
     dev, s, occ, n_rows = _case(3, seed=131)

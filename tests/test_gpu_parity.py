@@ -15,7 +15,7 @@ DEV = "cuda:0"
 
 @pytest.fixture(autouse=True)
 def _no_heavy_path_by_default(heavy_threshold):
-    # the bit-identical-sums assertions hold for voxels summed by ONE wavefront; keep the workgroup path
+    # the bit-identical-sums assertions hold for voxels summed by ONE wavefront; keep the split-voxel path
     # (different, fixed summation tree) out of those tests.  test_heavy_voxels_* lowers it again.
     heavy_threshold(100000000)
 
@@ -217,7 +217,7 @@ def test_heavy_voxels_use_the_workgroup_path(oracle_mod, heavy_threshold):
         _, got2, _ = _compare(oracle_mod, feats, s.occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size,
                               s.n_vox + 1, bitwise=False)
         assert got.tobytes() == got2.tobytes()
-    # an ID labelling several cells AND heavy: whole-image fallback of the workgroup path
+    # an ID labelling several cells AND heavy: the parts come up short, k_combine_parts redoes the voxel over whole images
     occ = np.where(s.occ > 0, (s.occ % 5) + 1, 0).astype(np.int32)
     feats = make_features_np(5, 32, 48, 8, seed=32)[None]
     _compare(oracle_mod, feats, occ[None], s.c2w, s.intr, s.opts(), s.grid_origin, s.voxel_size, 7,
@@ -731,7 +731,7 @@ def test_randomized_differential_against_the_oracle(oracle_mod):
 def test_randomized_job_mode_against_the_oracle(oracle_mod, heavy_threshold):
     # the raw API the way a job drives it: batches of grids (B 1..3), many views per call (up to 70), sequences of
     # pipelined or plain calls accumulating into the same outputs, fp32 or fp16 feature maps, heavy-voxel thresholds
-    # low enough to send voxels down the workgroup path, the optional per-view hit counter.  Counts and view counts
+    # low enough to split voxels into parts, the optional per-view hit counter.  Counts and view counts
     # exact, sums within 1e-4 of the oracle's float64 accumulation.
     import voxproj_host
     dev = torch.device(DEV)

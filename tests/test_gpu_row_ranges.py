@@ -1,6 +1,6 @@
 """Row ranges of phase 2 (VP_OPT_ROW_BEGIN / _END + VP_FLAG_GATHER_ONLY): a call cut into [0, h) and [h, n_rows) leaves
 exactly what one call leaves, bit for bit -- every voxel is summed by the same kernel role in both forms (one wavefront, or
-the workgroup role for voxels above the heavy threshold, whose list the ranged gathers share) -- and the rows below h are
+the split of voxels above the heavy threshold into parts, planned per range) -- and the rows below h are
 final as soon as the first gather is over: what a multi-GPU job needs to start their all-reduce under the second gather.
 With VP_FLAG_SERIAL_SUMS those bits are the oracle's.  No counterpart in the reference (single GPU, one atomicAdd per channel)."""
 import numpy as np
@@ -70,9 +70,9 @@ def test_blocking_call_cut_into_row_ranges(oracle_mod, V, half):
 
 @pytest.mark.parametrize("V", [3, 9])
 def test_heavy_voxels_of_a_ranged_call_take_the_workgroup_path_once(oracle_mod, V):
-    """With the production threshold lowered to 6 pixels most voxels of the scene take the workgroup path, whose list is the
-    march's -- the whole call's.  The ranged gathers share it: each takes the listed IDs inside its own range (few views: the
-    heavy voxels' own launch; many: the merged role), none is summed twice, and the result is the unsplit call's bit for bit."""
+    """With the production threshold lowered to 6 pixels most voxels of the scene are summed in parts, planned per row range from
+    the whole call's pixel histogram: every ranged gather plans the voxels of its own range, none is summed twice, and the result
+    is the unsplit call's bit for bit (a voxel's parts depend on its pixel count and boxes alone)."""
     import voxproj_host
     dev, s, feats, t = _setup(V, 32, seed=163 + V)
     n_rows = s.n_vox + 1
@@ -95,7 +95,7 @@ def test_heavy_voxels_of_a_ranged_call_take_the_workgroup_path_once(oracle_mod, 
     assert np.array_equal(res[0][0], ref_c) and np.array_equal(res[1][0], ref_c)
     assert res[0][1].tobytes() == res[1][1].tobytes()                       # split == whole, bit for bit
     scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
-    assert (np.abs(res[0][1] - ref_o) / scale).max() <= 1e-4                # the workgroup role's fixed tree vs the serial order
+    assert (np.abs(res[0][1] - ref_o) / scale).max() <= 1e-4                # parts combined in slot order vs the serial order
 
 
 def test_job_mode_with_every_call_cut_in_two(oracle_mod):
@@ -121,7 +121,7 @@ def test_job_mode_with_every_call_cut_in_two(oracle_mod):
     torch.cuda.synchronize()
     got_c, got_o = count.cpu().numpy(), out.cpu().numpy()
     assert np.array_equal(got_c, ref_c)
-    # the two whole calls of the five may take the workgroup path for heavy voxels: its sums differ in the last bits
+    # the two whole calls of the five may split heavy voxels into parts: their sums differ in the last bits
     scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
     assert (np.abs(got_o - ref_o) / scale).max() <= 1e-4
     ws.release()

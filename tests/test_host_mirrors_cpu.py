@@ -1,10 +1,14 @@
 """Host-side mirrors of the reference's packing script (prepare_tensor_data.py) on the CPU: camera conventions,
 JSON schema, feature up-sampling contract, and the tensor_data.pt schema."""
 import json
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _rot(rng):
@@ -161,3 +165,28 @@ def test_npy_layout_reads_the_header_only(tmp_path):
     np.save(tmp_path / "s.npy", np.zeros(3, dtype=[("x", "f4"), ("y", "i2")]))
     assert agg._npy_layout(str(tmp_path / "s.npy")) is None
     assert agg._granted_cpus() >= 1
+
+
+def test_bench_colour_loop_restatement_equals_the_oracle(oracle_mod):
+    """bench.py's cpu_torch_loop of the R4 leg -- the reference's colour loop (debug_project_colors.py:58-73) as a vectorised
+    torch-CPU expression -- against oracle.rgb_project (pinned by the reference's own run): colours, voxels and pixels equal."""
+    import importlib.util
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module_colours", os.path.join(ROOT, "bench.py"))
+        bm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bm)
+    finally:
+        sys.argv = argv
+    from synthetic_scene import make_scene
+    s = make_scene(3000, 3, 72, 48, seed=9, room=(5.0, 4.0, 2.4))
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (48, 72, 3), dtype=np.uint8)
+    for v in range(3):
+        colors, zyx, uv = oracle_mod.rgb_project(s.occ, s.c2w[v], s.intr, s.grid_origin, s.voxel_size, img)
+        c2, z2, uv2 = bm.colour_projection_torch_cpu(torch.from_numpy(s.occ), torch.from_numpy(s.c2w[v]), torch.from_numpy(s.intr),
+                                                     torch.from_numpy(s.grid_origin), s.voxel_size, torch.from_numpy(img))
+        assert colors.shape[0] > 500
+        assert np.array_equal(z2.numpy(), zyx) and np.array_equal(uv2.numpy(), uv)
+        assert c2.numpy().tobytes() == colors.tobytes()

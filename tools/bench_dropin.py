@@ -23,13 +23,31 @@ import project_features_front as front  # noqa: E402
 import voxproj_host  # noqa: E402
 from synthetic_scene import make_features_torch, make_scene  # noqa: E402
 
-SHAPES = {"R2": (200000, 968, 548, 512), "R1": (80000, 484, 274, 512)}
+SHAPES = {"R2": (200000, 968, 548, 512), "R1": (80000, 484, 274, 512),
+          # the hand-held trajectory legs of bench.py (round 5): --view-ids picks frames (0 = close-up dwell, ~130 = the look through the opening)
+          "A1": (87319, 876, 584, 512), "R2T": (200000, 968, 548, 512)}
 
 
-def run(shape, occ_modes, fronts, NV, reps, phases):
+def _bench_module():
+    import importlib.util
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+        bm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bm)
+    finally:
+        sys.argv = argv
+    return bm
+
+
+def run(shape, occ_modes, fronts, NV, reps, phases, view_ids=None):
     dev = torch.device("cuda", 0)
     n_vox, W, H, C = SHAPES[shape]
-    s = make_scene(n_vox, 300 if shape == "R2" else 100, W, H, seed=0)
+    s = _bench_module().workload_scene(shape) if shape in ("A1", "R2T") else make_scene(n_vox, 300 if shape == "R2" else 100, W, H, seed=0)
+    if view_ids:
+        s.c2w = s.c2w[view_ids]
+        NV = len(view_ids)
     feats = make_features_torch(NV, H, W, C, dev, seed=0)
     occ32 = torch.from_numpy(s.occ).to(dev)
     occ = occ32.unsqueeze(0).long().contiguous()
@@ -61,7 +79,7 @@ def run(shape, occ_modes, fronts, NV, reps, phases):
                     fn(feats[v:v + 1].unsqueeze(0), o, vm[v], intr, opts, count, out, pm, origin, s.voxel_size)
                 ts.append((time.perf_counter() - t0) / NV)
             t = min(ts)
-            line = (f"{shape} {'fresh occupancy tensor per call' if fresh else 'same occupancy tensor':32s} {name:9s} {t * 1e3:.4f} ms/call  "
+            line = (f"{shape}{' views ' + ','.join(map(str, view_ids)) if view_ids else ''} {'fresh occupancy tensor per call' if fresh else 'same occupancy tensor':32s} {name:9s} {t * 1e3:.4f} ms/call  "
                     f"{n_vox / t / 1e6:.0f} Mvoxel-views/s  {algo / t / 1e9:.0f} GB/s algorithmic = {algo / t / 8e12:.3f} of peak "
                     f"({W * H * C * 4 / t / 1e9:.0f} GB/s of feature-map bytes)")
             if phases:
@@ -78,7 +96,8 @@ def run(shape, occ_modes, fronts, NV, reps, phases):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="both", choices=("R2", "R1", "both"))
+    ap.add_argument("--shape", default="both", choices=("R2", "R1", "both", "A1", "R2T"))
+    ap.add_argument("--view-ids", default="", help="comma-separated frames of the workload's camera path (default: its first --views)")
     ap.add_argument("--occ", default="both", choices=("same", "fresh", "both"))
     ap.add_argument("--front", default="both", choices=("compiled", "python", "both"))
     ap.add_argument("--views", type=int, default=16)
@@ -92,7 +111,8 @@ def main():
         voxproj_host.set_default_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view)
     for shape in (("R2", "R1") if a.shape == "both" else (a.shape,)):
         run(shape, {"same": (False,), "fresh": (True,), "both": (False, True)}[a.occ],
-            ("compiled", "python") if a.front == "both" else (a.front,), a.views, a.reps, a.phases)
+            ("compiled", "python") if a.front == "both" else (a.front,), a.views, a.reps, a.phases,
+            [int(v) for v in a.view_ids.split(",")] if a.view_ids else None)
 
 
 if __name__ == "__main__":
