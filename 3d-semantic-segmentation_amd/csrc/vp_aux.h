@@ -21,7 +21,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 enum { CST_BADID = 0, CST_DUP = 1 };
 #ifndef COLOR_UNROLL
-#define COLOR_UNROLL 1     // views whose pixel gathers are in flight together per lane of k_project_colors
+#define COLOR_UNROLL 2     // views whose pixel gathers are in flight together per lane of k_project_colors
 #endif
 constexpr int COLOR_CHUNK = 64;   // views whose pose and intrinsics are staged in LDS together
 
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict
     const int r = live ? cell - z * (dimy * dimx) : 0;
     const int y = r / dimx, x = r - y * dimx;
     const double wx = (double)ox + vs * (double)x, wy = (double)oy + vs * (double)y, wz = (double)oz + vs * (double)z;   // DPC:60
+    const long long img_bytes = (long long)V * img_h * img_w * 3;
     float sr = 0.f, sg = 0.f, sb = 0.f;
     int hc = 0, fv = 0;
     if (live) {
@@ -111,15 +112,20 @@ __global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict
             }
             // the pixel's three bytes with ONE load (an unaligned dword; the fourth byte belongs to the next pixel and is
             // dropped): 64 lanes x 3 byte loads to 64 different cache lines kept the CU's one address unit busy longer than
-            // the arithmetic took.  The last pixel of an image is read byte by byte (nothing may lie behind it).
+            // the arithmetic took.  Branch-free, so that the loads of the group go out back to back: a lane without a pixel
+            // loads the first dword of the images, and the dword of the very last pixel of the last image starts one byte
+            // early (nothing may be read behind the buffer).
             unsigned pix[COLOR_UNROLL];
 #pragma unroll
             for (int j = 0; j < COLOR_UNROLL; j++) {
-                pix[j] = 0u;
-                if (ui[j] >= 0) {
-                    const unsigned char *px = img + (((long long)(vc + v0 + j) * img_h + vi[j]) * img_w + ui[j]) * 3;
-                    if (ui[j] == img_w - 1 && vi[j] == img_h - 1) pix[j] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
-                    else __builtin_memcpy(&pix[j], px, 4);
+                const long long off = ui[j] >= 0 ? (((long long)(vc + v0 + j) * img_h + vi[j]) * img_w + ui[j]) * 3 : 0;
+                if (img_bytes >= 4) {
+                    const long long ld = min(off, img_bytes - 4);
+                    unsigned w4;
+                    __builtin_memcpy(&w4, img + ld, 4);
+                    pix[j] = w4 >> (8 * (int)(off - ld));
+                } else {      // a single pixel in all: byte by byte
+                    pix[j] = (unsigned)img[off] | ((unsigned)img[off + 1] << 8) | ((unsigned)img[off + 2] << 16);
                 }
             }
 #pragma unroll

@@ -108,7 +108,7 @@ def parse():
     ap.add_argument("--views", type=int, default=0, help="override the number of views (0 = workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="plain calls: phase 1 and 2 serial on one stream")
-    ap.add_argument("--cpu-views", type=int, default=8, help="views in the cpu_baseline sample")
+    ap.add_argument("--cpu-views", type=int, default=96, help="views in the cpu_baseline sample (about 10 s on 16 cores at R2; the single-thread sample is an eighth of it)")
     ap.add_argument("--dtype", default="f32", choices=("f32", "f16"), help="feature-map storage type; f32 is the "
                     "BASELINE metric config, f16 the lossless half-bandwidth mode of SURVEY 8f/n4 (extra, not the headline)")
     ap.add_argument("--rehearse-dist", action="store_true", help="with one process: create the process group anyway (RCCL "
@@ -236,6 +236,32 @@ def write_pmc_json(prof_dir, out_path):
     return doc
 
 
+def write_r4_pmc_json(prof_dir, out_path, views_per_call=1000):
+    """profiles/<tag>_r4_pmc.json from the counter CSVs of tools/r4_round.sh (k_project_colors), stamped with the digest of the
+    kernel sources: HBM-side bytes per launch and what the waves did with their cycles."""
+    import collections
+    import csv
+    import glob
+    c = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_project_colors" in r["Kernel_Name"]:
+                c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    m = {k: sum(v) / len(v) for k, v in c.items()}
+    summary = {"wave_cycles_parked_on_memory": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3),
+               "wave_cycles_issue_stalled": round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3),
+               # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs
+               "valu_busy_of_simd_cycles": round(m["SQ_ACTIVE_INST_VALU"] * 4 / (m["GRBM_GUI_ACTIVE"] / 8 * 1024), 3),
+               "valu_instructions_per_voxel_view": round(m["SQ_INSTS_VALU"] * 64 / (500000.0 * views_per_call), 1),
+               "l2_misses_per_launch": int(m["TCC_MISS_sum"]), "l2_hits_per_launch": int(m["TCC_HIT_sum"]), "waves": int(m["SQ_WAVES"])}
+    doc = {"source": "rocprofv3 --pmc passes of python3 bench.py --workload R4 --steps 1 --warmup 0 --no-cpu-baseline (tools/r4_round.sh), MI355X",
+           "source_digest": source_digest(), "views_per_call": views_per_call,
+           "FETCH_SIZE_KB_per_launch": round(m["FETCH_SIZE"], 1), "WRITE_SIZE_KB_per_launch": round(m["WRITE_SIZE"], 1), "summary": summary}
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1)
+    return doc
+
+
 def host_cores():
     """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (a one-GPU box of
     the pool shows 256 logical CPUs but grants 16; 256 OpenMP threads on that share run the oracle 7x slower)."""
@@ -250,19 +276,31 @@ def host_cores():
     return n
 
 
-def cpu_baseline(scene, C, n_views, n_threads):
-    """Time the CPU oracle (port of project_image_cuda_kernel.cu:24-92,157-187) on n_views views."""
+_cpu_maps = {}
+
+
+def cpu_baseline(scene, C, n_views, n_threads, maps=4):
+    """Time the CPU oracle (port of project_image_cuda_kernel.cu:24-92,157-187) on n_views views of the workload, `maps` at a time
+    (every chunk has its own poses and reads the same `maps` synthetic feature maps: generating 1 GB maps on the host costs
+    more than marching them, and the oracle's work does not depend on their values)."""
     from oracle import oracle
     from synthetic_scene import make_features_np
-    feats = make_features_np(n_views, scene.height, scene.width, C, seed=0)[None]
+    key = (scene.height, scene.width, C, maps)
+    if key not in _cpu_maps:
+        _cpu_maps.clear()
+        _cpu_maps[key] = make_features_np(maps, scene.height, scene.width, C, seed=0)[None]
+    feats = _cpu_maps[key]
     n_rows = scene.n_vox + 1
     count = np.zeros(n_rows, np.int32)
     out = np.zeros((n_rows, C), np.float32)
     occ = scene.occ[None].astype(np.int64)
-    t0 = time.perf_counter()
-    oracle.project_features(feats, occ, scene.c2w[:n_views].reshape(-1), scene.intr[None], scene.opts(),
-                            scene.grid_origin, scene.voxel_size, count, out, want_hits=False, nthreads=n_threads)
-    dt = time.perf_counter() - t0
+    dt = 0.0
+    for a in range(0, n_views, maps):
+        b = min(n_views, a + maps)
+        t0 = time.perf_counter()
+        oracle.project_features(feats[:, :b - a], occ, scene.c2w[a:b].reshape(-1), scene.intr[None], scene.opts(),
+                                scene.grid_origin, scene.voxel_size, count, out, want_hits=False, nthreads=n_threads)
+        dt += time.perf_counter() - t0
     return dict(value=round(scene.n_vox * n_views / dt / 1e6, 4), unit="Mvoxel-views/s", cores=n_threads, kind="port",
                 sample=f"{n_views} of the workload's views at full resolution, all {scene.n_vox} voxels, "
                        f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices; {os.cpu_count()} logical CPUs "
@@ -417,10 +455,23 @@ def bench_colors(a, dev, rank, world, dist):
     if rank == 0:
         n_seen = int(seen.item())
         per_call_hits = n_seen / max(1, len(calls) * world)
-        # algorithmic bytes of one call: 3 B per sampled pixel, the ID->cell table build (one pass over the dense grid),
-        # 4 B cell index + read-modify-write of {3 floats, count, first view} per voxel, pose + intrinsics per view
-        algo = per_call_hits * 3 + occ.numel() * 4 + (N + 1) * (4 + 2 * 20) + chunk * 80
+        # Algorithmic bytes of one call.  The gather is voxel-driven, one pixel per voxel and view, and the voxels' projections
+        # cover the images densely: about every 64-byte line of every image is needed once (1000 views: 130 M samples, 103 M L2
+        # misses, FETCH_SIZE 6.6 GB against 6.14 GB of images -- profiles/r05_r4_counters.txt), so the compulsory traffic is the
+        # image bytes themselves (or 64 B per sample where the samples are too few to cover them), plus the ID->cell table build
+        # (one pass over the dense grid), 4 B cell index + read-modify-write of {3 floats, count, first view} per voxel, pose +
+        # intrinsics per view.  (Rounds 1-4 counted 3 B per sample: 0.03 "of peak" for a kernel that streams 3.3 TB/s.)
+        img_bytes = min(per_call_hits * 64, chunk * H * W * 3)
+        algo = img_bytes + occ.numel() * 4 + (N + 1) * (4 + 2 * 20) + chunk * 80
         ach = algo / (call_ms * 1e-3) / 1e9
+        r4pmc = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_r4_pmc.json")) as f:
+                r4pmc = json.load(f)
+            if r4pmc.get("source_digest") != source_digest() or r4pmc.get("views_per_call") != chunk:
+                r4pmc = None
+        except OSError:
+            pass
         res = {"metric": "Mvoxel-views/sec", "value": round(N * V / (dt / a.steps) / 1e6, 1), "unit": "Mvoxel-views/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 projection, f32 colour sums",
@@ -430,13 +481,20 @@ def bench_colors(a, dev, rank, world, dist):
                           "parallelism": f"views r::{world} per GPU + one RCCL {a.collective} of colour sums/counts per pass" if world > 1 else "single GPU"},
                "voxel_view_hits_per_step": n_seen,
                "roofline": {"bound": "hbm", "kernel": "vp_project_colors (k_color_cells + k_project_colors)", "achieved": round(ach, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                            "traffic": (int((r4pmc["FETCH_SIZE_KB_per_launch"] + r4pmc["WRITE_SIZE_KB_per_launch"]) * 1024) if r4pmc else None),
+                            "traffic_source": "profiles/r05_r4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, taken as read: "
+                                              "the x2 correction of gfx950 applies to 16-B-per-lane streaming reads, these are 4-byte gathers, and "
+                                              "FETCH_SIZE here equals TCC_MISS x 64 B) -- not measured in this run",
                             "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4),
-                            "note": "3 bytes gathered per voxel-view after ~60 float64 operations: latency / fp64-ALU bound, "
-                                    "no HBM-roofline claim (SURVEY 8d)"}}
+                            "counters": (r4pmc.get("summary") if r4pmc else None),
+                            "note": "HBM line-gather bound: one 4-byte load per voxel and view pulls a 64-byte line, about every line of "
+                                    "every image once; the waves wait for those lines 82 % of their cycles (VALU busy 36 %: ~50 float64 "
+                                    "instructions per voxel-view incl. two IEEE divisions) -- SURVEY 8d waives the roofline claim for R4, "
+                                    "the counters are the evidence for what bounds it"}}
         if not a.no_cpu_baseline and world == 1:
             from oracle import oracle
-            nv = min(4, V)
+            nv = min(400, V)                                           # ~10 s on one core
             img_np = imgs[0].cpu().numpy()
             t1 = time.perf_counter()
             for v in range(nv):
@@ -445,7 +503,7 @@ def bench_colors(a, dev, rank, world, dist):
             res["cpu_baseline"] = dict(value=round(N * nv / dtc / 1e6, 3), unit="Mvoxel-views/s", cores=1, kind="port",
                                        sample=f"{nv} of the workload's views, all {N} voxels, {dtc:.1f} s wall "
                                               "(oracle_rgb_project: scalar C restatement of debug_project_colors.py:54-81)")
-            res["cpu_torch_loop"] = cpu_colour_loop(s, img_np, min(8, V), host_cores())
+            res["cpu_torch_loop"] = cpu_colour_loop(s, img_np, min(400, V), host_cores())
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -620,6 +678,9 @@ def launch_check(a, rank, world):
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--write-r4-pmc":
+        print(json.dumps(write_r4_pmc_json(sys.argv[2], sys.argv[3])))
+        return
     if len(sys.argv) == 4 and sys.argv[1] == "--write-pmc-json":
         print(json.dumps(write_pmc_json(sys.argv[2], sys.argv[3]))[:300])
         return
@@ -883,17 +944,24 @@ def main():
     if dist is not None and h_rows > 0 and arm_arg == "auto":
         # Which arm is faster depends on the links, the backend and the rank count (gloo rehearsals on one GPU: split 160 vs whole
         # 171 ms at 2 ranks, 2117 vs 353 ms at 4) and no 8-GPU node was ever available to measure it: the timed arm is chosen from
-        # a short untimed calibration of both -- 2 steps each, bracketed like the timed region, MAX over ranks (so that every rank
-        # picks the same arm).  Both arms still run and are reported.
+        # a short untimed calibration of both -- three steps each, alternating, every step bracketed like the timed region and
+        # MAX-reduced over the ranks (so that every rank picks the same arm), the median per arm.  Both arms still run and are
+        # reported.
         calibration = {}
         for arm_split in (True, False):
-            step_dist(arm_split)                                   # one step to settle (RCCL sizes its channels by message size)
-            barrier()
-            t_c = time.perf_counter()
             for _ in range(2):
+                step_dist(arm_split)                               # two steps each to settle (RCCL sizes its channels by message size; gloo
+                                                                   # sets up its staging per tensor: 17-s steps on first touches at 4 ranks)
+        per_arm = {True: [], False: []}
+        for rep in range(3):                                       # alternating, so that a drift hits both arms alike
+            for arm_split in (True, False):
+                barrier()
+                t_c = time.perf_counter()
                 step_dist(arm_split)
-            barrier()
-            calibration["split" if arm_split else "whole"] = round(_max_over_ranks(dist, time.perf_counter() - t_c, dev) / 2 * 1e3, 3)
+                barrier()
+                per_arm[arm_split].append(_max_over_ranks(dist, time.perf_counter() - t_c, dev))
+        for arm_split in (True, False):                            # the median of three steps, MAX over ranks each
+            calibration["split" if arm_split else "whole"] = round(sorted(per_arm[arm_split])[1] * 1e3, 3)
         default_split = calibration["split"] <= calibration["whole"]
     for _ in range(a.warmup):
         step()
@@ -1061,8 +1129,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only (bench contract)
             ncores = host_cores()
             res["cpu_baseline"] = cpu_baseline(scene, C, min(a.cpu_views, n_views), ncores)
-            res["cpu_baseline_1t"] = cpu_baseline(scene, C, min(2, n_views), 1)          # the oracle single-threaded too
-            res["cpu_torch_loop"] = cpu_torch_loop(scene, min(16, n_views), ncores)
+            res["cpu_baseline_1t"] = cpu_baseline(scene, C, max(1, min(a.cpu_views // 8, n_views)), 1)      # the oracle single-threaded too
+            res["cpu_torch_loop"] = cpu_torch_loop(scene, min(300, n_views), ncores)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,6 +18,7 @@ step fetch rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o c --output-format csv -- 
 step write rocprofv3 --pmc WRITE_SIZE -d $out/write -o c --output-format csv -- $one
 step tcc rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $out/tcc -o c --output-format csv -- $one
 python3 tools/summarize_prof.py $out/trace $out/sq1 $out/sq2 $out/sq3 $out/fetch $out/write $out/tcc > $out/summary.txt 2>&1
+python3 bench.py --write-r4-pmc $out gpurun_out/${tag}_r4_pmc.json
 find $out -name "*kernel_trace.csv" -size +5M -delete
 grep "k_project_colors\|k_color_cells\|^==\|^--" $out/summary.txt
 grep -h '^{' $out/trace.log | cut -c1-600

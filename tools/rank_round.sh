@@ -7,10 +7,10 @@
 # 2. the whole 300-view scene with 2 and with 4 ranks started by bench.py itself (`--gpus N`, no launcher), gloo, all ranks on
 #    this GPU: exactness of the reduced scene (bench.py asserts counts exactly, sums per channel) -- timings mean nothing here.
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 cd "$GRAFT_REPO_ROOT" || exit 1
 o=gpurun_out
-pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); c=d.get("collective",{}); print(json.dumps({k:d[k] for k in ("n_gpus","value","ms_per_step","hit_pixels_per_step","reduced_hit_pixels") if k in d}), json.dumps({"views_per_call":d["config"]["views_per_call"],"arms":c.get("arms"),"timed_arm":c.get("timed_arm"),"exposed_ms":c.get("collective_ms_exposed"),"projection_ms":c.get("projection_ms_per_step"),"backend":c.get("backend"),"gather_frac":d["roofline"]["frac"],"avg_launch_ms":d["roofline"]["avg_launch_ms"]}))'
+pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); c=d.get("collective",{}); print(json.dumps({k:d[k] for k in ("n_gpus","value","ms_per_step","hit_pixels_per_step","reduced_hit_pixels") if k in d}), json.dumps({"views_per_call":d["config"]["views_per_call"],"arms":c.get("arms"),"timed_arm":c.get("timed_arm"),"chosen_by":c.get("timed_arm_chosen_by"),"calibration":c.get("calibration"),"per_rank":c.get("per_rank"),"collectives":c.get("collectives_per_pass"),"exposed_ms":c.get("collective_ms_exposed"),"projection_ms":c.get("projection_ms_per_step"),"backend":c.get("backend"),"gather_frac":d["roofline"]["frac"],"avg_launch_ms":d["roofline"]["avg_launch_ms"]}))'
 {
 echo "# one rank's share through the multi-rank step, one-rank RCCL communicator (python3 bench.py --rehearse-dist --views N --no-cpu-baseline)"
 for v in 150 75 38; do
