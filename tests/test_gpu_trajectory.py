@@ -323,3 +323,37 @@ def test_split_voxels_whose_boxes_miss_pixels_are_redone_over_whole_images(oracl
     assert np.array_equal(count_t.cpu().numpy(), count)
     assert (views_t.cpu().numpy()[1:6] == 6).all()
     _rows_within_bar(out_t.cpu().numpy(), r["out64"], count > 0)
+
+
+def test_part_size_is_raised_to_the_slot_bound_when_it_binds(oracle_mod):
+    """Rows of 32 KiB (C = 8192): 64 MiB of partial rows per buffer set are 2048 part slots, and a call of 24 576 pixels asked to
+    cut voxels into 6-pixel parts could outnumber them -- both thresholds are raised to ceil(2 * B*V*H*W / slots) = 24 (reported
+    through the counters), parts are planned with that size, results stay within the bar."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    V, C = 8, 8192
+    s = make_scene(2000, V, 64, 48, seed=91, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(V, 48, 64, C, seed=91)[None]
+    n_rows = s.n_vox + 1
+    count = np.zeros(n_rows, np.int32)
+    out = np.zeros((n_rows, C), np.float32)
+    r = oracle_mod.project_features(feats, s.occ[None].astype(np.int64), s.c2w.reshape(-1), s.intr[None], s.opts(), s.grid_origin,
+                                    s.voxel_size, count, out, want_f64=True)
+    ws = voxproj_host.Workspace()
+    ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, 6)
+    ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 6)
+    count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    out_t = torch.zeros(n_rows, C, device=dev)
+    voxproj_host.project_features_raw(torch.from_numpy(feats).to(dev), torch.from_numpy(s.occ[None].astype(np.int64)).to(dev),
+                                      torch.from_numpy(s.c2w).reshape(-1).to(dev), torch.from_numpy(s.intr[None]).to(dev),
+                                      [float(v) for v in s.opts()], count_t, out_t, [float(v) for v in s.grid_origin], s.voxel_size,
+                                      workspace=ws, sync=True)
+    ctr = voxproj_host.counters(ws, dev)
+    bound = -(-2 * V * 64 * 48 // 2048)
+    assert bound == 24 and ctr["heavy_t"] == bound, ctr
+    heavy = count > bound
+    assert ctr["n_heavy"] == int(heavy.sum()) > 50 and ctr["n_parts"] == int(np.ceil(count[heavy] / float(bound)).sum()) <= 2048
+    assert np.array_equal(count_t.cpu().numpy(), count)
+    got = out_t.cpu().numpy()
+    assert got[~heavy].tobytes() == out[~heavy].tobytes()
+    _rows_within_bar(got, r["out64"], heavy)

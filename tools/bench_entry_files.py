@@ -1,7 +1,8 @@
 """The named entry point end to end ON FILES, at the reference pipeline's own sizes (AGG:28,106,209: 87 319 voxels, DSLR
 images 1752x1168 worked at 0.5x = 876x584, LSeg maps fp16 [512,360,540] = 199 MB per view): writes N synthetic .npy maps, a
 voxel-grid PLY and a camera JSON into a scratch directory and times aggregate_voxel_features_onthefly.main() per view, with
-and without the feature feeder (--prefetch), in both modes.  One JSON line.  python tools/bench_entry_files.py [N]"""
+and without the feature feeder (--prefetch), in both modes.  One JSON line.
+python tools/bench_entry_files.py [N] [prefetch depths, e.g. 0,3] [trajectory]"""
 import json
 import os
 import shutil
@@ -18,8 +19,10 @@ from synthetic_scene import make_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 PREFETCH = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 3]     # feeder depths to time
+TRAJECTORY = len(sys.argv) > 3 and sys.argv[3] == "trajectory"     # the A1 leg's hand-held trajectory (0.04-m cells) instead of the benign room
 C, h, w = 512, 360, 540
-s = make_scene(87319, N, 876, 584, seed=0)
+s = (make_scene(87319, N, 876, 584, seed=0, trajectory=True, room=(4.4, 3.5, 2.5), voxel_size=0.04) if TRAJECTORY
+     else make_scene(87319, N, 876, 584, seed=0))
 tmp = tempfile.mkdtemp(prefix="vp_entry_")
 try:
     ply = os.path.join(tmp, f"scene_{s.n_vox}vox_grid.ply")
