@@ -306,7 +306,12 @@ inline long long part_slot_cap(int B, int V, int H, int W, int C)
 {
     const long long px2 = 2ll * B * V * (long long)H * W;
     const long long by_bytes = std::max<long long>(1024, ((long long)VP_MAX_SLOTS * 2048) / (std::max(C, 1) * 4ll));
-    return std::max<long long>(64, std::min<long long>(VP_MAX_SLOTS, std::min(px2, by_bytes)));
+    long long cap = std::max<long long>(64, std::min<long long>(VP_MAX_SLOTS, std::min(px2, by_bytes)));
+    // a call of ONE view cuts voxels into parts only through the general gather kernel (VP_OPT_ONE_VIEW_GATHER = 0, the A/B arm),
+    // with parts of 320 pixels by default: 4096 slots (8 MiB at C = 512) cover a view of 650 k pixels -- the drop-in module's
+    // scratch buffer should not carry 2 x 64 MiB it never touches
+    if ((long long)B * V == 1) cap = std::min<long long>(cap, 4096);
+    return cap;
 }
 
 Layout make_layout(int B, int V, int H, int W, int C, long long n_rows, int dimz, int dimy, int dimx, size_t capacity = 0)
