@@ -62,11 +62,14 @@ SCENE_NAME = {"A1": "hand-held trajectory scene seed 0 (close-up dwells, opening
               "R2T": "hand-held trajectory scene seed 0 (close-up dwells, opening in a wall and the ceiling, clutter 0.5)"}
 
 
+SCENE_SEED = 0      # --scene-seed: another clutter layout and hand tremor (trajectory legs) / other poses and boxes (benign room)
+
+
 def workload_scene(name, n_views=None, W=None, H=None):
     """The synthetic scene of a named workload (n_views / W / H override the workload's: tests march reduced images)."""
     from synthetic_scene import make_scene
     n_vox, V, w, h, _ = WORKLOADS[name]
-    return make_scene(n_vox, n_views or V, W or w, H or h, seed=0, **SCENE_KW.get(name, {}))
+    return make_scene(n_vox, n_views or V, W or w, H or h, seed=SCENE_SEED, **SCENE_KW.get(name, {}))
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -148,6 +151,9 @@ def parse():
                     help="multi-rank step: which collective arm the timed region runs.  auto (default) = a short untimed calibration "
                          "of both arms (2 steps each, MAX over ranks) picks the faster one; the other arm runs after the timed "
                          "region either way and both are reported (collective.arms, collective.calibration)")
+    ap.add_argument("--scene-seed", type=int, default=0,
+                    help="seed of the synthetic scene (default 0 = the scene every committed number is quoted on; other seeds: another "
+                         "clutter layout and hand tremor on the trajectory legs -- a check that nothing is tuned to one scene)")
     ap.add_argument("--no-other-arm", action="store_true",
                     help="multi-rank step: skip the steps of the other collective arm after the timed region")
     ap.add_argument("--launch-check", action="store_true",
@@ -685,6 +691,8 @@ def main():
         print(json.dumps(write_pmc_json(sys.argv[2], sys.argv[3]))[:300])
         return
     a = parse()
+    global SCENE_SEED
+    SCENE_SEED = a.scene_seed
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         return launch_ranks(a)                   # the parent: no GPU call before, none after
     rank = int(os.environ.get("RANK", "0"))
@@ -1078,7 +1086,7 @@ def main():
             "dtype": "f32" if a.dtype == "f32" else "f32 accumulate, f16 feature maps",
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {n_vox} voxels x {n_views} views x {W}x{H}x{C} {'fp32' if a.dtype == 'f32' else 'fp16'} feature maps, "
-                                   f"{SCENE_NAME.get(a.workload, 'room-shell scene seed 0')}, dmin 0.01 dmax 10 step 0.5*voxel",
+                                   f"{SCENE_NAME.get(a.workload, 'room-shell scene seed 0').replace('seed 0', 'seed ' + str(a.scene_seed))}, dmin 0.01 dmax 10 step 0.5*voxel",
                        "views_per_call": chunk, "resident_feature_maps": pool,
                        "parallelism": (f"views r::{world} per GPU + one RCCL {'reduce to rank 0' if a.collective == 'reduce' else 'all-reduce'} of sum/count "
                                        f"per pass, waited for inside the pass (backend {a.dist_backend})")
