@@ -509,10 +509,6 @@ __device__ __forceinline__ void gather_part_wave(const GatherArgs &g, const Para
     const float hh = box_half_edge(p);
     const float zn = near_plane(p);
     constexpr int CB = 64 * K * VEC;
-#ifdef VP_PART_JITTER
-    // experiment: parts start up to ~200 us apart (do the parts of a close-up call, all of one size, march through memory in step?)
-    for (int i = 0, n = (int)((unsigned)(slot * 2654435761u) >> 27); i < n * 2; i++) __builtin_amdgcn_s_sleep(127);
-#endif
     // pass 1: the voxel's total box area over the call's views
     long long A = 0;
     for (int b = 0; b < p.B; b++) {
