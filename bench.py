@@ -495,9 +495,9 @@ def bench_colors(a, dev, rank, world, dist):
                             "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4),
                             "counters": (r4pmc.get("summary") if r4pmc else None),
                             "note": "HBM line-gather bound: one 4-byte load per voxel and view pulls a 64-byte line, about every line of "
-                                    "every image once; the waves wait for those lines 82 % of their cycles (VALU busy 36 %: ~50 float64 "
-                                    "instructions per voxel-view incl. two IEEE divisions) -- SURVEY 8d waives the roofline claim for R4, "
-                                    "the counters are the evidence for what bounds it"}}
+                                    "every image once; the waves wait for those lines ~80 % of their cycles, the VALU is busy ~40 % (~50 float64 "
+                                    "instructions per voxel-view incl. two IEEE divisions): `counters`, from the committed passes -- SURVEY 8d "
+                                    "waives the roofline claim for R4, the counters are the evidence for what bounds it"}}
         if not a.no_cpu_baseline and world == 1:
             from oracle import oracle
             nv = min(400, V)                                           # ~10 s on one core
