@@ -357,3 +357,51 @@ def test_part_size_is_raised_to_the_slot_bound_when_it_binds(oracle_mod):
     got = out_t.cpu().numpy()
     assert got[~heavy].tobytes() == out[~heavy].tobytes()
     _rows_within_bar(got, r["out64"], heavy)
+
+
+def test_a_single_voxel_that_collects_nearly_the_whole_call(oracle_mod):
+    """The far end of "a camera stares at one surface": a grid of 1-m cells with ONE occupied cell a metre in front of twelve
+    cameras -- a voxel of several hundred thousand pixels, hundreds of parts whose partial rows k_combine_parts adds up four
+    wavefronts abreast.  Counts and view counts exact, the row within the bar, two runs bit-identical."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    V, W, H, C = 12, 256, 192, 64
+    occ = np.zeros((1, 5, 5, 5), np.int64)
+    occ[0, 2, 2, 2] = 1
+    occ[0, 4, 4, 4] = 2                                     # a second voxel in a corner: a few pixels at most
+    origin = np.array([-2.0, -2.0, -2.0], np.float32)       # the big voxel's centre is the world origin
+    rng = np.random.default_rng(17)
+    c2w = np.zeros((V, 4, 4), np.float32)
+    for v in range(V):
+        a = 2.0 * np.pi * v / V
+        pos = np.array([1.6 * np.cos(a), 1.6 * np.sin(a), 0.2 * np.sin(3 * a)])
+        f = -pos / np.linalg.norm(pos)
+        right = np.cross(f, np.array([0.0, 0.0, 1.0])); right /= np.linalg.norm(right)
+        down = np.cross(f, right)
+        c2w[v, :3, 0], c2w[v, :3, 1], c2w[v, :3, 2], c2w[v, :3, 3] = right, down, f, pos
+        c2w[v, 3, 3] = 1.0
+    intr = np.array([[0.9 * W, 0.9 * W, W / 2.0, H / 2.0]], np.float32)
+    opts = np.array([W, H, 0.01, 8.0, 0.25], np.float32)
+    feats = (rng.standard_normal((1, V, H, W, C)) + 0.5).astype(np.float32)     # a mean: every element of the row is 'solid'
+    count = np.zeros(3, np.int32)
+    out = np.zeros((3, C), np.float32)
+    r = oracle_mod.project_features(feats, occ, c2w.reshape(-1), intr, opts, origin, 1.0, count, out, want_f64=True)
+    assert r["rc"] == 0 and count[1] > 150000, count
+    ws = voxproj_host.Workspace()
+    res = []
+    for rep in range(2):
+        count_t = torch.zeros(3, dtype=torch.int32, device=dev)
+        out_t = torch.zeros(3, C, device=dev)
+        views_t = torch.zeros(3, dtype=torch.int32, device=dev)
+        voxproj_host.project_features_raw(torch.from_numpy(feats).to(dev), torch.from_numpy(occ).to(dev), torch.from_numpy(c2w).reshape(-1).to(dev),
+                                          torch.from_numpy(intr).to(dev), [float(v) for v in opts], count_t, out_t, [float(v) for v in origin], 1.0,
+                                          workspace=ws, sync=True, views_hit=views_t)
+        res.append((count_t.cpu().numpy(), out_t.cpu().numpy(), views_t.cpu().numpy()))
+    ctr = voxproj_host.counters(ws, dev)
+    heavy = count > 1024                                    # the corner voxel's ~1 k pixels may be just above the threshold too
+    assert ctr["heavy_t"] == 1024 and ctr["n_heavy"] == int(heavy.sum()) and ctr["box_miss"] == 0, ctr
+    assert ctr["n_parts"] == int(np.ceil(count[heavy] / 1024.0).sum()) > 150, ctr
+    hits = voxproj_host.hit_image(ws, dev).cpu().numpy()
+    assert np.array_equal(hits, r["hits"]) and np.array_equal(res[0][0], count)
+    assert res[0][2][1] == V and res[0][1].tobytes() == res[1][1].tobytes()
+    _rows_within_bar(res[0][1], r["out64"], count > 0)
