@@ -590,7 +590,8 @@ int vp_copy_hit_image(const void *workspace, int32_t *dst, int B, int V, int H, 
 size_t vp_colors_workspace_bytes(int64_t n_rows)
 {
     if (n_rows <= 0) return 0;
-    return 256 + align256(size_t(n_rows) * sizeof(int));
+    // status words | cell of every ID | the voxel list {ID, cell} in curve order | one count per walking wavefront
+    return 256 + align256(size_t(n_rows) * sizeof(int)) + align256(size_t(n_rows) * sizeof(int2)) + align256(size_t(COLOR_WALKERS) * sizeof(int));
 }
 
 int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx, const float *c2w, const float *intr,
@@ -611,20 +612,39 @@ int vp_project_colors(const int32_t *occ, int dimz, int dimy, int dimx, const fl
     hipStream_t stream = (hipStream_t)stream_;
     int *status = (int *)workspace;
     int *cell_of_id = (int *)((char *)workspace + 256);
+    int2 *list = (int2 *)((char *)cell_of_id + align256(size_t(n_rows) * sizeof(int)));
+    int *counts = (int *)((char *)list + align256(size_t(n_rows) * sizeof(int2)));
     VP_HIP(hipMemsetAsync(status, 0, 256, stream));
     VP_HIP(hipMemsetAsync(cell_of_id, 0xFF, size_t(n_rows) * sizeof(int), stream));
-    const int cb = (int)((cells + 255) / 256 > 16384 ? 16384 : (cells + 255) / 256);
-    hipLaunchKernelGGL(k_color_cells, dim3(cb), dim3(256), 0, stream, (const int *)occ, cells, cell_of_id, (long long)n_rows, status);
+    // the Morton curve over the grid's 4x4x4 blocks, shared by wavefronts that take 64 or more positions each
+    ColorCurve curve;
+    curve.nbx = (dimx + 3) / 4; curve.nby = (dimy + 3) / 4; curve.nbz = (dimz + 3) / 4;
+    const auto bits = [](int n) { int b = 0; while ((1 << b) < n) b++; return b; };
+    curve.bx = bits(curve.nbx); curve.by = bits(curve.nby); curve.bz = bits(curve.nbz);
+    curve.slots = 1ll << (curve.bx + curve.by + curve.bz);       // < 2^32: < 8 x the blocks of a grid of < 2^31 cells
+    const long long want = (curve.slots + 63) / 64;
+    const int walkers = (int)(want > COLOR_WALKERS ? COLOR_WALKERS : (want + 3) / 4 * 4);
+    hipLaunchKernelGGL(k_color_cells<1>, dim3(walkers / 4), dim3(256), 0, stream, (const int *)occ, dimz, dimy, dimx, curve,
+                       cell_of_id, (long long)n_rows, status, counts, list);
+    hipLaunchKernelGGL(k_color_scan, dim3(1), dim3(1024), 0, stream, counts, walkers, status);
+    hipLaunchKernelGGL(k_color_cells<2>, dim3(walkers / 4), dim3(256), 0, stream, (const int *)occ, dimz, dimy, dimx, curve,
+                       cell_of_id, (long long)n_rows, status, counts, list);
     int st[2];
     VP_HIP(hipMemcpyAsync(st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
     VP_HIP(hipStreamSynchronize(stream));
     if (st[CST_BADID]) return fail(VP_EBADID, "an occupancy ID is outside [1, n_rows): outputs are too small for the grid's IDs");
     if (st[CST_DUP]) return fail(VP_EINVAL, "an occupancy ID labels more than one cell: the colour path needs unique IDs "
                                             "(build_sparse_occupancy.py:44-46 produces them)");
-    hipLaunchKernelGGL(k_project_colors, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const int *)cell_of_id,
-                       dimy, dimx, c2w, intr, V, grid_origin_host[0], grid_origin_host[1], grid_origin_host[2],
-                       voxel_size, (const unsigned char *)images, img_h, img_w, color_sum, (int *)hit_count,
-                       (int *)first_view, (int *)pixel_uv, (long long)n_rows, view_base);
+    const bool tiny = (long long)V * img_h * img_w * 3 < 4;
+#define VP_LAUNCH_COLORS(UV, TINY)                                                                                           \
+    hipLaunchKernelGGL((k_project_colors<UV, TINY>), dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,           \
+                       (const int *)cell_of_id, (const int2 *)list, (const int *)status, dimy, dimx, c2w, intr, V,           \
+                       grid_origin_host[0], grid_origin_host[1], grid_origin_host[2], voxel_size,                            \
+                       (const unsigned char *)images, img_h, img_w, color_sum, (int *)hit_count, (int *)first_view,          \
+                       (int *)pixel_uv, (long long)n_rows, view_base)
+    if (pixel_uv) { if (tiny) VP_LAUNCH_COLORS(true, true); else VP_LAUNCH_COLORS(true, false); }
+    else          { if (tiny) VP_LAUNCH_COLORS(false, true); else VP_LAUNCH_COLORS(false, false); }
+#undef VP_LAUNCH_COLORS
     VP_HIP(hipGetLastError());
     VP_HIP(hipStreamSynchronize(stream));
     return VP_OK;

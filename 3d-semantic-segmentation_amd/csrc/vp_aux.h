@@ -8,36 +8,126 @@ namespace {
 // RGB path (BASELINE config 5): the reference's debug_project_colors.py:54-81 is a per-voxel Python loop --
 // voxel-driven, nearest pixel, NO occlusion test, numpy float64 arithmetic.
 //
-//   k_color_cells     one pass over the dense grid: cell_of_id[id] = cell (IDs are unique per cell when the grid comes
+//   k_color_cells<1>  one pass over the dense grid in Z-ORDER (4x4x4 blocks, one per wavefront load, the blocks along the
+//                     Morton curve of their coordinates): cell_of_id[id] = cell (IDs are unique per cell when the grid comes
 //                     from build_sparse_occupancy.py:44-46; an ID found in two cells raises CST_DUP, an ID outside
-//                     [1, n_rows) CST_BADID)
-//   k_project_colors  one lane per OCCUPIED voxel (the compact ID list, not the dense grid): the lane walks the views
+//                     [1, n_rows) CST_BADID) and the number of occupied cells of every wavefront's stretch of the curve
+//   k_color_scan      exclusive scan of those counts (one workgroup)
+//   k_color_cells<2>  the same walk again: the occupied cells' {ID, cell} appended in curve order -- the voxel list
+//   k_project_colors  one lane per entry of that list: the lane walks the views
 //                     of the call in order, so the voxel's float32 colour sum is accumulated in view order exactly like
 //                     aggregate_voxel_colors_onthefly.py:134-140 does (one contribution per view, no atomics), and
 //                     writes the pixel (u, v) it sampled per view (DPC:76, `pixel_indices`).
+// Why a list in curve order (round 5): which lane sums which voxel changes no bit of any output, but it decides which image
+// lines a wavefront, a workgroup and an XCD touch together.  With the lanes in ID order -- the scan order of the grid,
+// BSO:44-46 -- k_project_colors took 2.02 ms per 1000 views of config 5; with the same IDs relabelled along the curve on the
+// host 1.47-1.51 ms, and every coarser grouping in between (blocks of 4 / 8 / 16 / 32 cells in scan order: 1.66 / 1.62 / 1.55 /
+// 1.49 ms; profiles/r05_ab_colour_order.log): locality pays at every scale, so the list follows the curve itself.
 // Arithmetic contract: oracle_rgb_project in oracle/projector_oracle.c (separate multiplies and adds in float64, IEEE
 // divide, round-half-even).  img/255.0 is taken from a 256-entry table of exactly that float64 quotient rounded to
 // float32 (DPC:70,75), built in LDS by the workgroup: three correctly-rounded float64 divisions fewer per voxel-view.
 // ------------------------------------------------------------------------------------------------
-enum { CST_BADID = 0, CST_DUP = 1 };
+enum { CST_BADID = 0, CST_DUP = 1, CST_NOCC = 2 };
 #ifndef COLOR_UNROLL
-#define COLOR_UNROLL 2     // views whose pixel gathers are in flight together per lane of k_project_colors
+#define COLOR_UNROLL 2     // views per group of k_project_colors: their pixel loads go out together
 #endif
 constexpr int COLOR_CHUNK = 64;   // views whose pose and intrinsics are staged in LDS together
+constexpr int COLOR_WALKERS = 8192;   // wavefronts that share the curve (their counts are one workgroup's scan)
 
-__global__ __launch_bounds__(256) void k_color_cells(const int *__restrict__ occ, long long cells, int *cell_of_id,
-                                                     long long n_rows, int *status)
+struct ColorCurve {      // the Morton curve over the grid's 4x4x4 blocks: bits per axis (an axis that runs out of bits drops out)
+    int bx, by, bz;      // bits of the block coordinates
+    int nbx, nby, nbz;   // blocks per axis
+    long long slots;     // 2^(bx + by + bz) positions on the curve (those outside the grid are skipped)
+};
+
+__device__ __forceinline__ void curve_block(const ColorCurve &c, unsigned s, int &x, int &y, int &z)
 {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
-        const int id = occ[i];
-        if (id <= 0) continue;                            // DPC:50 (occ > 0)
-        if (id >= n_rows) { atomicOr(&status[CST_BADID], 1); continue; }
-        if (atomicMax(&cell_of_id[id], (int)i) >= 0) atomicOr(&status[CST_DUP], 1);
+    x = y = z = 0;
+    const int top = max(c.bx, max(c.by, c.bz));
+    for (int l = 0; l < top; l++) {
+        if (l < c.bx) { x |= (int)(s & 1u) << l; s >>= 1; }
+        if (l < c.by) { y |= (int)(s & 1u) << l; s >>= 1; }
+        if (l < c.bz) { z |= (int)(s & 1u) << l; s >>= 1; }
     }
 }
 
-__global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict__ cell_of_id, int dimy, int dimx,
+// PASS 1: cell_of_id, the error flags and counts[w] = occupied cells on wavefront w's stretch of the curve.
+// PASS 2: counts[] now holds the exclusive scan; {ID, cell} of the stretch's occupied cells go to list[counts[w] ...].
+// A wavefront decodes 64 curve positions at a time (one per lane) and then takes the blocks inside the grid eight at a time,
+// lane = cell of the block: eight independent 64-cell loads in flight.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_color_cells(const int *__restrict__ occ, int dimz, int dimy, int dimx, ColorCurve c,
+                                                     int *cell_of_id, long long n_rows, int *status, int *counts, int2 *list)
+{
+    const int lane = threadIdx.x & 63;
+    const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long s0 = c.slots * w / nw, s1 = c.slots * (w + 1) / nw;
+    const int lx = lane & 3, ly = (lane >> 2) & 3, lz = lane >> 4;
+    const long long base = PASS == 2 ? counts[w] : 0;
+    int n = 0;
+    for (long long sb = s0; sb < s1; sb += 64) {
+        int bxv, byv, bzv;
+        curve_block(c, (unsigned)(sb + lane), bxv, byv, bzv);
+        unsigned long long todo = __ballot(sb + lane < s1 && bxv < c.nbx && byv < c.nby && bzv < c.nbz);
+        while (todo) {
+            int id[8], cell[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                id[u] = 0; cell[u] = 0;
+                if (todo) {
+                    const int k = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int x = __builtin_amdgcn_readlane(bxv, k) * 4 + lx, y = __builtin_amdgcn_readlane(byv, k) * 4 + ly;
+                    const int z = __builtin_amdgcn_readlane(bzv, k) * 4 + lz;
+                    if (x < dimx && y < dimy && z < dimz) {
+                        cell[u] = (z * dimy + y) * dimx + x;
+                        id[u] = occ[cell[u]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                bool ok = id[u] > 0;                                  // DPC:50 (occ > 0)
+                if (ok && id[u] >= n_rows) { ok = false; if (PASS == 1) atomicOr(&status[CST_BADID], 1); }
+                if (PASS == 1) {
+                    if (ok && atomicMax(&cell_of_id[id[u]], cell[u]) >= 0) atomicOr(&status[CST_DUP], 1);
+                    n += __popcll(__ballot(ok));
+                } else {
+                    const unsigned long long m = __ballot(ok);
+                    const long long pos = base + n + __popcll(m & ((1ull << lane) - 1ull));
+                    if (ok && pos < n_rows) list[pos] = make_int2(id[u], cell[u]);      // pos < n_rows whenever the IDs are unique
+                    n += __popcll(m);
+                }
+            }
+        }
+    }
+    if (PASS == 1 && lane == 0) counts[w] = n;
+}
+
+// counts[0 .. n) -> their exclusive scan in place, the total to status[CST_NOCC].  One workgroup of 1024 lanes.
+__global__ __launch_bounds__(1024) void k_color_scan(int *counts, int n, int *status)
+{
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024, lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; i++) { const int v = counts[i]; counts[i] = run; run += v; }
+    if (threadIdx.x == 1023) status[CST_NOCC] = part[1023];
+}
+
+// UV: pixel_uv is written (DPC's diagnostics); TINY: the images hold fewer than four bytes in all (one pixel), read byte by byte.
+template <bool UV, bool TINY>
+__global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict__ cell_of_id, const int2 *__restrict__ list,
+                                                        const int *__restrict__ status, int dimy, int dimx,
                                                         const float *__restrict__ c2w, const float *__restrict__ intr,
                                                         int V, float ox, float oy, float oz, double vs,
                                                         const unsigned char *__restrict__ img, int img_h, int img_w,
@@ -51,17 +141,17 @@ __global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict
     // wavefront -- the kernel spent 55 % of its wave cycles parked (profiles/r05_r4_counters.txt).
     __shared__ double cam[COLOR_CHUNK][16];
     lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);                                                    // DPC:70,75
-    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = id < n_rows;
-    const int cell = (live && id > 0) ? cell_of_id[id] : -1;        // row 0 is the dummy of the 1-based IDs
-    if (live && cell < 0) {
-        if (pixel_uv)
-            for (int v = 0; v < V; v++) {
-                pixel_uv[((long long)v * n_rows + id) * 2 + 0] = -1;
-                pixel_uv[((long long)v * n_rows + id) * 2 + 1] = -1;
-            }
-        live = false;
-    }
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // rows no cell carries (row 0, the dummy of the 1-based IDs -- SURVEY Q4 -- among them) are seen by no view
+    if (UV && t < n_rows && (t == 0 || cell_of_id[t] < 0))
+        for (int v = 0; v < V; v++) {
+            pixel_uv[((long long)v * n_rows + t) * 2 + 0] = -1;
+            pixel_uv[((long long)v * n_rows + t) * 2 + 1] = -1;
+        }
+    const bool live = t < status[CST_NOCC];      // entry t of the voxel list
+    const int2 entry = live ? list[t] : make_int2(0, 0);
+    const long long id = entry.x;
+    const int cell = entry.y;
     const int z = live ? cell / (dimy * dimx) : 0;
     const int r = live ? cell - z * (dimy * dimx) : 0;
     const int y = r / dimx, x = r - y * dimx;
@@ -85,64 +175,73 @@ __global__ __launch_bounds__(256, 8) void k_project_colors(const int *__restrict
             }
         }
         __syncthreads();
-        if (!live) continue;
         const int nv = min(COLOR_CHUNK, V - vc);
-        // Views are taken COLOR_UNROLL at a time: the pixel addresses of the group are computed first, their loads go out
-        // together, and the colours are added afterwards in view order (the float32 sums are the same bits as one view at a time).
-        for (int v0 = 0; v0 < nv; v0 += COLOR_UNROLL) {
-            int ui[COLOR_UNROLL], vi[COLOR_UNROLL];
+        if (!live) continue;
+        // Views are taken COLOR_UNROLL at a time and the groups are software-pipelined: while the pixel loads of one group
+        // are in flight the lane projects the voxel into the views of the NEXT group (~150 float64 instructions per view in sight,
+        // two IEEE divisions among them) and sends their loads; the colours are added afterwards in view order (the float32
+        // sums are the same bits as one view at a time).  Two register sets take turns, and the loads of a group go out in
+        // straight-line code, so that the wait in front of the sums counts loads instead of draining them (deeper rings were
+        // slower: profiles/r05_ab_colour_order.log).
+        // A pixel's three bytes come with ONE load (an unaligned dword; the fourth byte belongs to the next pixel and is
+        // dropped): 64 lanes x 3 byte loads to 64 different cache lines kept the CU's one address unit busy longer than
+        // the arithmetic took.  A lane without a pixel loads the first dword of the images, and the dword of the very last
+        // pixel of the last image starts one byte early (nothing may be read behind the buffer).
+        // `seen`: bit j = view j of the group sees the voxel; bits 8.. = the byte shift of load j (non-zero for that last pixel only).
+        const auto send = [&](int v0, unsigned (&pix)[COLOR_UNROLL]) -> unsigned {
+            unsigned seen = 0;
 #pragma unroll
             for (int j = 0; j < COLOR_UNROLL; j++) {
-                ui[j] = -1; vi[j] = -1;
-                if (v0 + j < nv) {
-                    const double *m = cam[v0 + j];
-                    const double dx = wx - m[9], dy = wy - m[10], dz = wz - m[11];                                  // DPC:61-63
-                    const double cx = m[0] * dx + m[1] * dy + m[2] * dz;                                            // R^T d
-                    const double cy = m[3] * dx + m[4] * dy + m[5] * dz;
-                    const double cz = m[6] * dx + m[7] * dy + m[8] * dz;
-                    if (cz > 0.0) {                                                                                 // DPC:65
-                        const double u = m[12] * (cx / cz) + m[14];                                                 // DPC:66-67
-                        const double w = m[13] * (cy / cz) + m[15];
-                        const double ur = rint(u), vr = rint(w);                                                    // DPC:68 (half to even)
-                        if (ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h) {                  // DPC:69
-                            ui[j] = (int)ur; vi[j] = (int)vr;
-                        }
+                int ui = -1, vi = -1;
+                const bool in_chunk = v0 + j < nv;
+                const double *m = cam[min(v0 + j, nv - 1)];
+                const double dx = wx - m[9], dy = wy - m[10], dz = wz - m[11];                                  // DPC:61-63
+                const double cx = m[0] * dx + m[1] * dy + m[2] * dz;                                            // R^T d
+                const double cy = m[3] * dx + m[4] * dy + m[5] * dz;
+                const double cz = m[6] * dx + m[7] * dy + m[8] * dz;
+                if (in_chunk && cz > 0.0) {                                                                   // DPC:65
+                    const double u = m[12] * (cx / cz) + m[14];                                                 // DPC:66-67
+                    const double w = m[13] * (cy / cz) + m[15];
+                    const double ur = rint(u), vr = rint(w);                                                    // DPC:68 (half to even)
+                    if (ur >= 0.0 && ur < (double)img_w && vr >= 0.0 && vr < (double)img_h) {                  // DPC:69
+                        ui = (int)ur; vi = (int)vr;
                     }
                 }
-            }
-            // the pixel's three bytes with ONE load (an unaligned dword; the fourth byte belongs to the next pixel and is
-            // dropped): 64 lanes x 3 byte loads to 64 different cache lines kept the CU's one address unit busy longer than
-            // the arithmetic took.  Branch-free, so that the loads of the group go out back to back: a lane without a pixel
-            // loads the first dword of the images, and the dword of the very last pixel of the last image starts one byte
-            // early (nothing may be read behind the buffer).
-            unsigned pix[COLOR_UNROLL];
-#pragma unroll
-            for (int j = 0; j < COLOR_UNROLL; j++) {
-                const long long off = ui[j] >= 0 ? (((long long)(vc + v0 + j) * img_h + vi[j]) * img_w + ui[j]) * 3 : 0;
-                if (img_bytes >= 4) {
+                if (UV && in_chunk) {
+                    pixel_uv[((long long)(vc + v0 + j) * n_rows + id) * 2 + 0] = ui;
+                    pixel_uv[((long long)(vc + v0 + j) * n_rows + id) * 2 + 1] = vi;
+                }
+                const long long off = ui >= 0 ? (((long long)(vc + v0 + j) * img_h + vi) * img_w + ui) * 3 : 0;
+                if (!TINY) {
                     const long long ld = min(off, img_bytes - 4);
-                    unsigned w4;
-                    __builtin_memcpy(&w4, img + ld, 4);
-                    pix[j] = w4 >> (8 * (int)(off - ld));
-                } else {      // a single pixel in all: byte by byte
+                    __builtin_memcpy(&pix[j], img + ld, 4);          // shifted when it is used: nothing here waits for the load
+                    seen |= (unsigned)(off - ld) << (8 + 2 * j);
+                } else {
                     pix[j] = (unsigned)img[off] | ((unsigned)img[off + 1] << 8) | ((unsigned)img[off + 2] << 16);
                 }
+                seen |= (ui >= 0 ? 1u : 0u) << j;
             }
+            return seen;
+        };
+        const auto add = [&](int v0, const unsigned (&pix)[COLOR_UNROLL], unsigned seen) {
 #pragma unroll
-            for (int j = 0; j < COLOR_UNROLL; j++) {
-                const int v = vc + v0 + j;
-                if (ui[j] >= 0) {
-                    sr += lut[pix[j] & 255u];                                                                       // AGGC:139
-                    sg += lut[(pix[j] >> 8) & 255u];
-                    sb += lut[(pix[j] >> 16) & 255u];
+            for (int j = 0; j < COLOR_UNROLL; j++)
+                if (seen >> j & 1u) {
+                    const unsigned px = pix[j] >> (8 * (seen >> (8 + 2 * j) & 3u));
+                    sr += lut[px & 255u];                                                                           // AGGC:139
+                    sg += lut[(px >> 8) & 255u];
+                    sb += lut[(px >> 16) & 255u];
                     hc += 1;                                                                                        // AGGC:140
-                    fv = min(fv, view_base + v);
+                    fv = min(fv, view_base + vc + v0 + j);
                 }
-                if (pixel_uv && v0 + j < nv) {
-                    pixel_uv[((long long)v * n_rows + id) * 2 + 0] = ui[j];
-                    pixel_uv[((long long)v * n_rows + id) * 2 + 1] = vi[j];
-                }
-            }
+        };
+        unsigned pix_a[COLOR_UNROLL], pix_b[COLOR_UNROLL];
+        unsigned seen_a = send(0, pix_a), seen_b;
+        for (int v0 = 0; v0 < nv; v0 += 2 * COLOR_UNROLL) {          // views past the chunk's end are sent to pixel 0 and dropped
+            seen_b = send(v0 + COLOR_UNROLL, pix_b);
+            add(v0, pix_a, seen_a);
+            seen_a = send(v0 + 2 * COLOR_UNROLL, pix_a);
+            add(v0 + COLOR_UNROLL, pix_b, seen_b);
         }
     }
     if (!live) return;

@@ -648,3 +648,60 @@ def test_feature_feeder_closes_its_files_on_errors_and_early_exits(tmp_path):
     import gc
     gc.collect()
     assert {f for f in open_fds() if str(tmp_path) in f} == before
+
+
+@pytest.mark.parametrize("dims,n_vox", [((1, 1, 1), 1), ((1, 1, 300), 40), ((3, 1, 2), 6), ((2, 130, 5), 300), ((70, 9, 33), 2500),
+                                         ((150, 170, 190), 3000), ((64, 64, 64), 64 ** 3), ((5, 4, 1030), 900)])
+def test_rgb_voxel_list_along_the_curve_on_awkward_grids(oracle_mod, dims, n_vox):
+    """k_color_cells walks the grid's 4x4x4 blocks along a Morton curve and k_project_colors sums the voxels in that order:
+    grids of one cell, of one row, with axes that are no multiple of four or run out of bits early, a full grid (every block
+    of the curve occupied), more curve positions than walking wavefronts.  Five views in two calls, with and without the
+    sampled pixels: sums (view order), hit counts, first views and pixels equal the oracle's bit for bit; IDs that label no
+    cell stay untouched."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(sum(dims) + n_vox)
+    Z, Y, X = dims
+    occ = np.zeros(dims, np.int32)
+    n_rows = n_vox + 4                                             # three IDs beyond the labelled ones: rows without a cell
+    occ.reshape(-1)[rng.choice(occ.size, n_vox, replace=False)] = rng.permutation(n_vox) + 1
+    vs = 0.05
+    origin = np.array([-0.5 * X * vs, -0.5 * Y * vs, -0.5 * Z * vs], np.float32)
+    V, iw, ih = 5, 96, 64
+    c2w = np.zeros((V, 4, 4), np.float32)
+    reach = 0.6 * vs * max(dims) + 0.5
+    for v in range(V):
+        a = 2.0 * np.pi * v / V + 0.3
+        pos = np.array([reach * np.cos(a), reach * np.sin(a), 0.3 * reach * np.sin(2 * a)])
+        f = -pos / np.linalg.norm(pos)
+        right = np.cross(f, np.array([0.0, 0.0, 1.0])); right /= np.linalg.norm(right)
+        c2w[v, :3, 0], c2w[v, :3, 1], c2w[v, :3, 2], c2w[v, :3, 3] = right, np.cross(f, right), f, pos
+        c2w[v, 3, 3] = 1.0
+    intr = np.tile(np.array([70.0, 72.0, iw / 2 + 0.5, ih / 2], np.float32), (V, 1))
+    imgs = rng.integers(0, 256, (V, ih, iw, 3), dtype=np.uint8)
+    ref_sum = np.zeros((n_rows, 3), np.float32)
+    ref_hits = np.zeros(n_rows, np.int32)
+    ref_first = np.full(n_rows, 2 ** 30, np.int32)
+    ref_uv = np.full((V, n_rows, 2), -1, np.int32)
+    for v in range(V):
+        colors, zyx, uv = oracle_mod.rgb_project(occ, c2w[v], intr[v], origin, vs, imgs[v])
+        ids = occ[zyx[:, 0], zyx[:, 1], zyx[:, 2]]
+        ref_sum[ids] += colors
+        ref_hits[ids] += 1
+        ref_first[ids] = np.minimum(ref_first[ids], 7 + v)
+        ref_uv[v, ids] = uv
+    assert ref_hits.sum() > 0
+    occ_t = torch.from_numpy(occ).to(dev)
+    for want_uv in (False, True):
+        csum = torch.zeros(n_rows, 3, device=dev)
+        hits = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        first = torch.full((n_rows,), 2 ** 30, dtype=torch.int32, device=dev)
+        uv_t = torch.full((V, n_rows, 2), 77, dtype=torch.int32, device=dev) if want_uv else None
+        for lo, hi in ((0, 3), (3, 5)):
+            voxproj_host.project_colors_raw(occ_t, torch.from_numpy(c2w[lo:hi]).to(dev), torch.from_numpy(intr[lo:hi]).to(dev),
+                                            [float(v) for v in origin], vs, torch.from_numpy(imgs[lo:hi]).to(dev), csum, hits,
+                                            first_view=first, view_base=7 + lo, pixel_uv=uv_t[lo:hi] if want_uv else None)
+        assert csum.cpu().numpy().tobytes() == ref_sum.tobytes()
+        assert np.array_equal(hits.cpu().numpy(), ref_hits) and np.array_equal(first.cpu().numpy(), ref_first)
+        if want_uv:
+            assert np.array_equal(uv_t.cpu().numpy(), ref_uv)

@@ -25,6 +25,35 @@ V, rounds = int(arg("--views", "1000")), int(arg("--rounds", "3"))
 N, W, H = 500000, 1752, 1168
 dev = torch.device("cuda", 0)
 s = make_scene(N, V, W, H, seed=0)
+order = arg("--order", "scan")
+if order != "scan":      # relabel the occupied cells (what a sorted ID list inside the library would give): "morton" = full Z-order of
+    # the cells; "blockN" = N x N x N blocks in scan order of the blocks (x fastest), Z-order inside a block
+    occ_np = s.occ
+    zz, yy, xx = np.nonzero(occ_np)
+
+    def spread(v):
+        v = v.astype(np.uint64)
+        out = np.zeros_like(v)
+        for b in range(12):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+
+    def morton(x, y, z):
+        return spread(x) | (spread(y) << np.uint64(1)) | (spread(z) << np.uint64(2))
+    if order == "morton":
+        key = morton(xx, yy, zz)
+    else:
+        n = int(order[5:])
+        dz, dy, dx = occ_np.shape
+        nbx, nby = -(-dx // n), -(-dy // n)
+        blk = ((zz // n).astype(np.uint64) * np.uint64(nby) + (yy // n).astype(np.uint64)) * np.uint64(nbx) + (xx // n).astype(np.uint64)
+        key = (blk << np.uint64(36)) | morton(xx % n, yy % n, zz % n)
+    rank = np.empty(len(key), np.int32)
+    rank[np.argsort(key, kind="stable")] = np.arange(1, len(key) + 1, dtype=np.int32)
+    occ_np = occ_np.copy()
+    occ_np[zz, yy, xx] = rank
+    s.occ = occ_np
+print("# grid", s.occ.shape, "voxel", s.voxel_size)
 occ = torch.from_numpy(s.occ).to(dev)
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 imgs = torch.randint(0, 256, (V, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
@@ -51,6 +80,7 @@ for rnd in range(rounds):
         if ref is None:
             ref = chk
         assert chk == ref, f"{path}: colour sums / counts / first views differ from the first arm's"
+print(f"# ID order: {order}")
 print(f"# R4: {N} voxels x {V} views, one blocking vp_project_colors call (k_color_cells + k_project_colors + a status read-back), "
       f"{rounds} rounds x 2 timed calls per arm, same bits from every arm")
 for path in libs:
