@@ -333,6 +333,22 @@ def colour_projection_torch_cpu(occ_zyx, c2w, intr4, grid_origin, voxel_size, im
     return colors, zyx[ok], torch.stack([ui, vi], 1)
 
 
+def distinct_image_lines(scene, views, H, W, dev):
+    """Distinct 64-byte lines of the [V,H,W,3] uint8 images that hold a pixel some voxel samples in `views` -- the compulsory
+    image traffic of one vp_project_colors call (H*W*3 is a multiple of 64 for config 5, so lines never span two images)."""
+    occ = torch.from_numpy(scene.occ).to(dev)
+    c2w = torch.from_numpy(scene.c2w).to(dev)
+    intr = torch.from_numpy(scene.intr).to(dev)
+    origin = torch.from_numpy(np.asarray(scene.grid_origin, dtype=np.float32)).to(dev)
+    blank = torch.zeros(H, W, 3, dtype=torch.uint8, device=dev)
+    n = 0
+    for v in views:
+        uv = colour_projection_torch_cpu(occ, c2w[v], intr, origin, scene.voxel_size, blank)[2]
+        off = (uv[:, 1] * W + uv[:, 0]) * 3
+        n += int(torch.unique(torch.cat([off // 64, (off + 2) // 64])).numel())
+    return n
+
+
 def cpu_colour_loop(scene, img_u8, n_views, n_threads):
     """cpu_torch_loop of the R4 leg: colour_projection_torch_cpu over n_views views on the box's host cores."""
     torch.set_num_threads(n_threads)
@@ -412,7 +428,7 @@ def bench_colors(a, dev, rank, world, dist):
     pixel, no occlusion (debug_project_colors.py:54-81 + aggregate_voxel_colors_onthefly.py:134-140).  One STEP = all 1000
     views through vp_project_colors in calls of --chunk views (default: all of a rank's views in one call; 1000 images are
     6.1 GB).  Three bytes are
-    gathered per voxel-view, so the kernel is latency / float64-ALU bound: the line carries the roofline object the
+    gathered per voxel-view, so the kernel is bound by scattered line fetches: the line carries the roofline object the
     contract asks for, with the honest fraction, and makes no roofline claim."""
     import voxproj_host
     from synthetic_scene import make_scene
@@ -461,14 +477,16 @@ def bench_colors(a, dev, rank, world, dist):
     if rank == 0:
         n_seen = int(seen.item())
         per_call_hits = n_seen / max(1, len(calls) * world)
-        # Algorithmic bytes of one call.  The gather is voxel-driven, one pixel per voxel and view, and the voxels' projections
-        # cover the images densely: about every 64-byte line of every image is needed once (1000 views: 130 M samples, 103 M L2
-        # misses, FETCH_SIZE 6.6 GB against 6.14 GB of images -- profiles/r05_r4_counters.txt), so the compulsory traffic is the
-        # image bytes themselves (or 64 B per sample where the samples are too few to cover them), plus the ID->cell table build
-        # (one pass over the dense grid), 4 B cell index + read-modify-write of {3 floats, count, first view} per voxel, pose +
-        # intrinsics per view.  (Rounds 1-4 counted 3 B per sample: 0.03 "of peak" for a kernel that streams 3.3 TB/s.)
-        img_bytes = min(per_call_hits * 64, chunk * H * W * 3)
-        algo = img_bytes + occ.numel() * 4 + (N + 1) * (4 + 2 * 20) + chunk * 80
+        # Algorithmic bytes of one call: every DISTINCT 64-byte line of an image that holds a sampled pixel has to come in once
+        # (images are not shared between views), counted exactly by a float64 torch restatement of the projection on the
+        # device (distinct_image_lines); plus the two passes over the dense grid that build the voxel list, 12 B of list and
+        # cell table + the read-modify-write of {3 floats, count, first view} per voxel, pose + intrinsics per view.
+        # (Rounds 1-4 counted 3 B per sample: 0.03 "of peak".  The first half of round 5 counted min(64 B per sample, image
+        # bytes) because the lane = voxel-ID kernel's L2 misses happened to equal the images' line count; with the voxels
+        # in curve order the kernel FETCHES 3.4 GB of the 6.1 GB, so that was no floor.)
+        lines = distinct_image_lines(s, my_views, H, W, dev) / len(calls)          # per call, like call_ms
+        img_bytes = lines * 64
+        algo = img_bytes + 2 * occ.numel() * 4 + (N + 1) * (12 + 2 * 20) + chunk * 80
         ach = algo / (call_ms * 1e-3) / 1e9
         r4pmc = None
         try:
@@ -494,10 +512,13 @@ def bench_colors(a, dev, rank, world, dist):
                                               "FETCH_SIZE here equals TCC_MISS x 64 B) -- not measured in this run",
                             "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4),
                             "counters": (r4pmc.get("summary") if r4pmc else None),
-                            "note": "HBM line-gather bound: one 4-byte load per voxel and view pulls a 64-byte line, about every line of "
-                                    "every image once; the waves wait for those lines ~80 % of their cycles, the VALU is busy ~40 % (~50 float64 "
-                                    "instructions per voxel-view incl. two IEEE divisions): `counters`, from the committed passes -- SURVEY 8d "
-                                    "waives the roofline claim for R4, the counters are the evidence for what bounds it"}}
+                            "distinct_image_lines_per_launch": int(lines),
+                            "note": "line-gather bound in the L1s, not in HBM: one 4-byte load per voxel and view pulls a 64-byte line; with the "
+                                    "voxels summed in Morton-curve order neighbouring lanes share lines (L2 misses 101 M -> 54 M, FETCH_SIZE 6.3 -> "
+                                    "3.4 GB per 1000 views) and the launch went from 2.0 to 1.4 ms, where an L1 spends about half of the launch stalled "
+                                    "behind lines already on their way (profiles/r05_ab_colour_order.log, section 8); skipping every view a "
+                                    "wavefront cannot see, deeper load pipelines and the cache-policy bits changed nothing or made it slower -- "
+                                    "SURVEY 8d waives the roofline claim for R4, `counters` (from the committed passes) and that log are the evidence"}}
         if not a.no_cpu_baseline and world == 1:
             from oracle import oracle
             nv = min(400, V)                                           # ~10 s on one core

@@ -201,7 +201,9 @@ int vp_profile_read(double *ms4, int64_t *launches4);
 /*
  * RGB path: replaces the per-voxel Python loop of DPC:54-81 plus the per-view accumulation of
  * aggregate_voxel_colors_onthefly.py:134-140 for a batch of V views (voxel-driven, nearest pixel, no
- * occlusion test, float64 arithmetic exactly as numpy promotes it there).  One lane per occupied voxel.
+ * occlusion test, float64 arithmetic exactly as numpy promotes it there).  One lane per occupied voxel; the
+ * lanes take the voxels along the Morton curve of the grid's cells (a list the call builds on the device), which
+ * changes no output bit and halves the image lines a launch fetches.
  *
  *   occ        i32 [dimz,dimy,dimx] device, > 0 = voxel ID (BSO:44-46; DPC:50 tests occ > 0).  Every ID must label
  *              exactly ONE cell (build_sparse_occupancy.py guarantees it); a duplicate returns VP_EINVAL
@@ -214,7 +216,7 @@ int vp_profile_read(double *ms4, int64_t *launches4);
  *                             dict insertion order of AGGC:136-137 on the host
  *   pixel_uv   i32 [V,n_rows,2] out or NULL: the pixel (u, v) sampled for voxel `id` in view v (DPC:76
  *                             `pixel_indices`), (-1,-1) where the voxel is not seen
- *   workspace  device scratch of >= vp_colors_workspace_bytes(n_rows) bytes, 256-byte aligned
+ *   workspace  device scratch of >= vp_colors_workspace_bytes(n_rows) bytes (12 per row + 33 KiB), 256-byte aligned
  * Synchronous (returns after the stream has drained).
  */
 size_t vp_colors_workspace_bytes(int64_t n_rows);
