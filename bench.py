@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-line-count", action="store_true", help="R4: skip the exact count of distinct image lines (an upper bound takes its place in bytes_per_launch)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["R4"],
                     help="R2 (default) = BASELINE metric config; R1 = config 2; S0 = config 1; R4 = config 5, the RGB path "
                          "(500k voxels x 1000 views, uint8 images; its own kernel, no HBM-roofline claim); A1 = the problem size the "
@@ -99,7 +100,7 @@ def parse():
     ap.add_argument("--call-gb", type=float, default=66.0,
                     help="feature-map bytes per call the automatic --chunk aims for (SURVEY 8d: chunks of <= 64 resident views, "
                          "69.5 GB).  Every call read-modify-writes the output rows it touches, and those stores cost far more "
-                         "than their bytes (DESIGN.md section 4): 60 views per call instead of 30 = +2.7 % on a slow-level box")
+                         "than their bytes (DESIGN.md section 4): 60 views per call instead of 30 = +2.7 %% on a slow-level box")
     ap.add_argument("--min-calls", type=int, default=None,
                     help="cut a rank's views into at least this many calls (in pipelined mode the march of every call but the "
                          "first hides under the previous gather).  Default 2 where passes follow one another (one GPU: the "
@@ -484,7 +485,10 @@ def bench_colors(a, dev, rank, world, dist):
         # (Rounds 1-4 counted 3 B per sample: 0.03 "of peak".  The first half of round 5 counted min(64 B per sample, image
         # bytes) because the lane = voxel-ID kernel's L2 misses happened to equal the images' line count; with the voxels
         # in curve order the kernel FETCHES 3.4 GB of the 6.1 GB, so that was no floor.)
-        lines = distinct_image_lines(s, my_views, H, W, dev) / len(calls)          # per call, like call_ms
+        if a.no_line_count:      # counter passes: a thousand views of torch kernels would swamp the profiler's tables
+            lines = min(per_call_hits, chunk * H * W * 3 / 64.0)
+        else:
+            lines = distinct_image_lines(s, my_views, H, W, dev) / len(calls)          # per call, like call_ms
         img_bytes = lines * 64
         algo = img_bytes + 2 * occ.numel() * 4 + (N + 1) * (12 + 2 * 20) + chunk * 80
         ach = algo / (call_ms * 1e-3) / 1e9
@@ -512,7 +516,7 @@ def bench_colors(a, dev, rank, world, dist):
                                               "FETCH_SIZE here equals TCC_MISS x 64 B) -- not measured in this run",
                             "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4),
                             "counters": (r4pmc.get("summary") if r4pmc else None),
-                            "distinct_image_lines_per_launch": int(lines),
+                            "distinct_image_lines_per_launch": (None if a.no_line_count else int(lines)),
                             "note": "line-gather bound in the L1s, not in HBM: one 4-byte load per voxel and view pulls a 64-byte line; with the "
                                     "voxels summed in Morton-curve order neighbouring lanes share lines (L2 misses 101 M -> 54 M, FETCH_SIZE 6.3 -> "
                                     "3.4 GB per 1000 views) and the launch went from 2.0 to 1.4 ms, where an L1 spends about half of the launch stalled "

@@ -25,7 +25,7 @@ for w in R2T A1; do
   rocprofv3 --pmc WRITE_SIZE -d $out/write_$w -o c --output-format csv -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_write_$w.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --stats -d $out/trace_$w -o t --output-format csv -- python3 bench.py --workload $w --no-cpu-baseline > $out/bench_${w}_under_rocprof.log 2>&1 || exit 1
 done
-rocprofv3 --kernel-trace --stats -d $out/trace_R4 -o t --output-format csv -- python3 bench.py --workload R4 --no-cpu-baseline > $out/bench_R4_under_rocprof.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $out/trace_R4 -o t --output-format csv -- python3 bench.py --workload R4 --no-cpu-baseline --no-line-count > $out/bench_R4_under_rocprof.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $out/trace_R1 -o t --output-format csv -- python3 bench.py --workload R1 --no-cpu-baseline > $out/bench_R1_under_rocprof.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $out/trace_entry_parity -o t --output-format csv -- python3 bench.py --entry parity --no-cpu-baseline > $out/bench_entry_parity_under_rocprof.log 2>&1 || exit 1
 python3 tools/summarize_prof.py $out/trace $out/trace_f16 $out/fetch_f32 $out/write_f32 $out/fetch_f16 $out/write_f16 $out/fetch_R1 $out/write_R1 $out/trace_R4 $out/trace_R1 $out/trace_R2T $out/fetch_R2T $out/write_R2T $out/trace_A1 $out/fetch_A1 $out/write_A1 > $out/summary.txt

@@ -9,7 +9,7 @@ out=gpurun_out/r4_$tag
 rm -rf $out; mkdir -p $out
 step() { local name=$1; shift; echo "[r4] $name $(date +%T)"; timeout -k 10 300 "$@" > $out/$name.log 2>&1; local rc=$?; echo "[r4] $name rc $rc"
          if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[r4] $name timed out: stopping"; exit $rc; fi; return 0; }
-one="python3 bench.py --workload R4 --steps 1 --warmup 0 --no-cpu-baseline"
+one="python3 bench.py --workload R4 --steps 1 --warmup 0 --no-cpu-baseline --no-line-count"
 step trace rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- $one
 step sq1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $out/sq1 -o c --output-format csv -- $one
 step sq2 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU -d $out/sq2 -o c --output-format csv -- $one
