@@ -190,3 +190,31 @@ def test_bench_colour_loop_restatement_equals_the_oracle(oracle_mod):
         assert colors.shape[0] > 500
         assert np.array_equal(z2.numpy(), zyx) and np.array_equal(uv2.numpy(), uv)
         assert c2.numpy().tobytes() == colors.tobytes()
+
+
+def test_bench_distinct_image_lines_against_a_brute_force_count(oracle_mod):
+    """bench.py's algorithmic bytes of the R4 leg: distinct 64-byte image lines that hold a sampled pixel, per view, against a
+    set built from the oracle's pixels."""
+    import importlib.util
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module_lines", os.path.join(ROOT, "bench.py"))
+        bm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bm)
+    finally:
+        sys.argv = argv
+    from synthetic_scene import make_scene
+    W, H = 64, 48                                                      # H*W*3 is a multiple of 64, like config 5's images
+    s = make_scene(3000, 3, W, H, seed=9, room=(5.0, 4.0, 2.4))
+    img = np.zeros((H, W, 3), np.uint8)
+    want = 0
+    for v in range(3):
+        uv = oracle_mod.rgb_project(s.occ, s.c2w[v], s.intr, s.grid_origin, s.voxel_size, img)[2]
+        lines = set()
+        for u, w in uv:
+            off = (int(w) * W + int(u)) * 3
+            lines.update((off // 64, (off + 2) // 64))
+        want += len(lines)
+    assert want > 100
+    assert bm.distinct_image_lines(s, [0, 1, 2], H, W, torch.device("cpu")) == want
