@@ -301,15 +301,40 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // has c > heavy_t >= part_px pixels and P = ceil(c / part_px) <= 2c / part_px parts, the c of a call add up to at most
     // B*V*H*W, so part_px >= 2*B*V*H*W / slots is enough -- both values are raised to that bound (only calls larger than the
     // bench's are: 32768 slots allow parts of 2048 pixels up to 33.5 M pixels per call).
-    int part_px = 0;
+    PlanArgs plan;
+    plan.heavy_t = heavy_t; plan.part_t = 2147483647; plan.part_px = 0; plan.count_heavy = 1; plan.dyn_px_min = 0; plan.dyn_t_ratio = 0;
+    plan.dyn_t_floor = 0; plan.cell_in_item = 0;
+    const long long px2 = 2ll * B * V * (long long)H * W;
+    // One-view calls (round 6) cut their large voxels into parts too -- one wavefront of k_gather_one per part, k_combine_parts
+    // behind it -- and size the parts on the device from the view's hit total (PlanArgs, vp_gather.h).  VP_OPT_ONE_VIEW_SPLIT = 0
+    // keeps round 5's path (a workgroup per voxel above 320 pixels) as the A/B arm.
+    const bool one_split = one_view && heavy_t != 2147483647 && rec.opt_one_view_split != 0;
     if (!one_view && heavy_t != 2147483647) {
         long long ppx = rec.opt_part_px > 0 ? rec.opt_part_px : std::max<long long>(1, heavy_t);     // VP_OPT_PART_PIXELS
-        const long long px2 = 2ll * B * V * (long long)H * W;
         ppx = std::max(ppx, (px2 + l.slot_cap - 1) / l.slot_cap);
-        part_px = (int)std::min<long long>(ppx, 2147483647ll);
-        heavy_t = std::max(heavy_t, part_px);
+        plan.part_px = (int)std::min<long long>(ppx, 2147483647ll);
+        heavy_t = std::max(heavy_t, plan.part_px);
+        plan.heavy_t = plan.part_t = heavy_t;
+    } else if (one_split) {
+        // fixed numbers where the options give them (VP_OPT_ONE_VIEW_SPLIT, else VP_OPT_HEAVY_THRESHOLD; VP_OPT_PART_PIXELS), raised
+        // to the slot bound like those of multi-view calls; otherwise the device's
+        const long long T = rec.opt_one_view_split > 0 ? rec.opt_one_view_split : rec.opt_heavy_t > 0 ? rec.opt_heavy_t : 0;
+        long long ppx = rec.opt_part_px > 0 ? std::max(rec.opt_part_px, (px2 + l.slot_cap - 1) / l.slot_cap) : 0;
+        if (ppx == 0 && T > 0) ppx = std::max<long long>((T + ONE_VIEW_T_RATIO - 1) / ONE_VIEW_T_RATIO, (px2 + l.slot_cap - 1) / l.slot_cap);
+        plan.part_px = (int)std::min<long long>(ppx, 2147483646ll);
+        plan.dyn_px_min = ppx > 0 ? 0 : ONE_VIEW_PART_MIN;
+        plan.heavy_t = plan.part_t = T > 0 ? (int)std::min<long long>(std::max(T, ppx), 2147483646ll) : 0;
+        plan.dyn_t_ratio = T > 0 ? 0 : ONE_VIEW_T_RATIO;
+        plan.dyn_t_floor = (long long)H * W <= GATHER_G32_SMALL_IMAGE ? ONE_VIEW_T_FLOOR_SMALL : 0;
+        plan.cell_in_item = 1;
+        heavy_t = plan.heavy_t;
+    } else if (one_view) {
+        plan.count_heavy = 0;      // the march enlists and counts the voxels above heavy_t
     }
-    if (gather_only) { heavy_t = st->last_heavy_t; part_px = st->last_part_px; }   // the thresholds of the call whose march is reused
+    static_assert(sizeof(PlanArgs) == sizeof(int) * 8, "PlanArgs is kept as ints in the workspace record");
+    if (gather_only) { memcpy(&plan, st->last_plan, sizeof(plan)); heavy_t = plan.heavy_t; }      // the thresholds of the call whose march is reused
+    const int part_px = plan.part_px;
+    const bool plans_parts = part_px > 0 || plan.dyn_px_min > 0;
 #ifdef VP_DIAG
     if (flags & VP_FLAG_DIAG_EVALS) heavy_t = -1;      // diagnostic build only: the hit image then holds evaluation counts
     if (flags & VP_FLAG_DIAG_WAVES) heavy_t = -2;      // ... per-wavefront clock stamps
@@ -317,10 +342,11 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const int wl_blocks = (int)((n_rows + 256 * WL_PER_THREAD - 1) / (256 * WL_PER_THREAD));
     int4 *parts = (int4 *)(ws + l.parts[q]), *split = (int4 *)(ws + l.split[q]), *pmeta = (int4 *)(ws + l.pmeta[q]);
     float *prow = (float *)(ws + l.prow[q]);
+    int *hit_waves = (int *)(ws + l.hitcnt[q]);
 #define VP_LAUNCH_WORKLIST(STREAM)                                                                                              \
     hipLaunchKernelGGL(k_worklist, dim3((unsigned)(wl_blocks + (B * V + 255) / 256)), dim3(256), 0, STREAM, (const int *)cnt_call,   \
-                       heavy_t, part_px, (long long)n_rows, work, status, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi, parts, split, \
-                       (int)l.slot_cap, rec.sticky_dev)
+                       plan, (long long)n_rows, work, status, wl_blocks, vmi, viewtab, B * V, row_lo, row_hi, parts, split, \
+                       (int)l.slot_cap, rec.sticky_dev, (const int *)cell_of_id, (const int *)hit_waves, (int)l.n_hitcnt)
     if (gather_only) {
         // the work list of the new row range, from the histogram the previous call's march left
         VP_HIP(hipMemsetAsync(status + ST_WORK0, 0, ST_PLAN_WORDS * sizeof(int), s0));
@@ -330,14 +356,15 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         ProfSpan sp; sp.begin(0, s1);
         // one launch clears the per-call status words and the per-call histogram, and checks the workspace header
         hipLaunchKernelGGL(k_zero_call, dim3((unsigned)((n_rows + 1023) / 1024)), dim3(256), 0, s1, status, cnt_call, (long long)n_rows,
-                           status0, rec.sticky_dev, WS_MAGIC, rec.gen, expect_tables);
+                           status0, rec.sticky_dev, WS_MAGIC, rec.gen, expect_tables, hit_waves, plan.dyn_px_min > 0 ? l.n_hitcnt : 0ll);
         sp.end();
     }
     if (!gather_only) {
         FirstHitArgs fa;
         fa.occ = (const long long *)occ; fa.vmi = vmi; fa.intr = intr; fa.near2 = near2; fa.dist = dist;
         fa.nby = l.nby; fa.nbx = l.nbx; fa.nblk = l.nblk; fa.hit = hit; fa.cnt_call = cnt_call;
-        fa.heavy_list = heavy_list; fa.heavy_t = (one_view || heavy_t < 0) ? heavy_t : 2147483647;      // (the march enlists heavy voxels for one-view calls only)
+        fa.heavy_list = heavy_list; fa.heavy_t = ((one_view && !one_split) || heavy_t < 0) ? heavy_t : 2147483647;      // (the march enlists heavy voxels for one-view calls without parts only)
+        fa.hit_waves = (plan.dyn_px_min > 0 && l.n_hitcnt > 0) ? hit_waves : nullptr;
         fa.status = status; fa.sticky = rec.sticky_dev;
         const dim3 grid((W + 15) / 16, (H + 15) / 16, B * V);
         ProfSpan sp; sp.begin(1, s1);
@@ -379,7 +406,8 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     g.row_lo = (int)row_lo; g.row_hi = (int)row_hi;
     g.work = work; g.work_n = status + ST_WORK0;
     g.parts = parts; g.split = split; g.pmeta = pmeta; g.prow = prow;
-    g.heavy_t = heavy_t; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
+    g.host_word = nullptr; g.host_seq = 0;
+    g.parts_on = (one_view && plans_parts) ? 1 : 0; g.slot_cap = (int)l.slot_cap; g.count = count; g.views_hit = views_hit; g.out = out; g.status = status;
     const int vec_ok = feats_f16 ? 2 : ((C % 4 == 0) && (((uintptr_t)feats & 15) == 0) && (((uintptr_t)out & 15) == 0)) ? 1 : 0;
     // grouped ID-tile fetch on small images needs views to group
     const bool small_image = (long long)B * V >= 8 && (long long)H * W <= GATHER_G32_SMALL_IMAGE;
@@ -400,12 +428,42 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
         // every workgroup of the grid takes heavy voxels first (round 5; rounds 1-4: the first 128): on a close-up frame EVERY
         // voxel of the view is heavy -- 300-400 of them -- and 128 workgroups summed them three apiece while the rest of the grid
         // had nothing to deal (0.70 ms per call instead of 0.3, profiles/r05_dropin_trajectory.log)
-        g.heavy_blocks = heavy_t != 2147483647 ? (int)nblk : 0;
+        g.heavy_blocks = (heavy_t != 2147483647 && !plans_parts) ? (int)nblk : 0;
+        // A BLOCKING call (the drop-in module's) launches k_combine_parts only if the view has split voxels: most frames of a
+        // walk through a room have none, and the empty launch is 6-7 us of a 0.14-0.3 ms call.  The gather's first wavefront
+        // writes the count (final since k_worklist) into the record's pinned page, tagged with this call's sequence number; the
+        // host, which would otherwise sleep in the stream synchronise, reads it a few microseconds into the gather -- long before
+        // the gather ends.  Nothing depends on the note arriving: without it (2 ms) the launch goes out as for any other call.
+        volatile int *note = nullptr;
+        if ((flags & VP_FLAG_SYNC) && plans_parts && n_rows > 1) {
+            rec.split_seq = (rec.split_seq + 1) & 0x7fffu;
+            note = rec.sticky_host + ST_HOST_NSPLIT;
+            *note = 0;
+            g.host_word = rec.sticky_dev + ST_HOST_NSPLIT; g.host_seq = (int)rec.split_seq;
+        }
         if (n_rows > 1) VP_DISPATCH_GATHER_ONE((long long)H * W <= GATHER_G32_SMALL_IMAGE, vec_ok, C, dim3(nblk), dim3(256), 0, s0, g, p);
         sp.end();
+        bool combine = n_rows > 1 && plans_parts;
+        if (combine && note) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 0;; spin++) {
+                const unsigned v = (unsigned)*note;
+                if ((v >> 31) && ((v >> 16) & 0x7fffu) == rec.split_seq) { combine = (v & 0xffffu) != 0; break; }
+                if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                __builtin_ia32_pause();
+            }
+        }
+        if (combine) {
+            // the split voxels' partial rows -> their rows in `out`
+            ProfSpan sc; sc.begin(3, s0);
+            const dim3 cgrid((unsigned)std::max<long long>(1, std::min<long long>(COMBINE_BLOCKS, l.slot_cap / 2)));
+            VP_DISPATCH_KVU(k_combine_parts, vec_ok, C, cgrid, dim3(256), 0, s0, g, p);
+            sc.end();
+        }
     } else if (n_rows > 1) {
         // one wavefront per item of the work list: at most one item per voxel row that is not split, plus the parts
-        const long long items = (n_rows - 1) + (part_px > 0 ? l.slot_cap : 0);
+        // (the parts of a call: at most 2 * pixels / part_px, and never more than the slots)
+        const long long items = (n_rows - 1) + (part_px > 0 ? std::min<long long>(l.slot_cap, px2 / part_px + 1) : 0);
         {
             ProfSpan sp; sp.begin(2, s0);
             const dim3 ggrid((unsigned)((items + 3) / 4));
@@ -434,7 +492,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     VP_HIP(hipGetLastError());
     st->last_B = B; st->last_V = V; st->last_H = H; st->last_W = W; st->last_C = C; st->last_q = q;
     st->last_f16 = feats_f16; st->last_feats = (const void *)feats; st->last_out = (const void *)out; st->last_count = (const void *)count;
-    st->last_vmi = (const void *)vmi; st->last_ranged = ranged; st->last_heavy_t = heavy_t; st->last_part_px = part_px;
+    st->last_vmi = (const void *)vmi; st->last_ranged = ranged; memcpy(st->last_plan, &plan, sizeof(plan));
     st->has_hit = true; st->hit_off = l.hit[q];
     hit_guard.keep = true;
     if (flags & VP_FLAG_SYNC) return workspace_status_impl(workspace, stream_, true);
@@ -788,6 +846,7 @@ int vp_workspace_set_option(void *workspace, int option, long long value)
     case VP_OPT_ROW_END:         rec->opt_row_end = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_ONE_VIEW_GATHER: rec->opt_one_view = value >= 0 ? value : -1; return VP_OK;
     case VP_OPT_PART_PIXELS:     rec->opt_part_px = value > 0 ? value : -1; return VP_OK;
+    case VP_OPT_ONE_VIEW_SPLIT:  rec->opt_one_view_split = value >= 0 ? value : -1; return VP_OK;
     default: return fail(VP_EINVAL, "unknown workspace option %d", option);
     }
 }

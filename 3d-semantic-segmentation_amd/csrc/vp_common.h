@@ -107,10 +107,12 @@ struct WsState {
     long long opt_row_begin = -1, opt_row_end = -1;     // VP_OPT_ROW_BEGIN / _END: phase 2 gathers IDs in [begin, end)
     long long opt_one_view = -1;                        // VP_OPT_ONE_VIEW_GATHER: 0 = one-view calls through k_gather (A/B arm)
     long long opt_part_px = -1;                         // VP_OPT_PART_PIXELS: pixels per part of a split voxel (-1: default)
+    long long opt_one_view_split = -1;                  // VP_OPT_ONE_VIEW_SPLIT: one-view calls cut voxels above this many pixels into parts (0: never)
     // arguments of the last vp_project_features call (VP_FLAG_GATHER_ONLY repeats its phase 2 on another row range)
     int last_B = 0, last_V = 0, last_H = 0, last_W = 0, last_C = 0, last_q = 0;
     bool last_f16 = false, last_ranged = false;
-    int last_heavy_t = 0, last_part_px = 0;
+    int last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // PlanArgs of the last call, as ints
+    unsigned split_seq = 0;                             // sequence number of the last blocking one-view call that polled ST_HOST_NSPLIT
     const void *last_feats = nullptr, *last_out = nullptr, *last_count = nullptr, *last_vmi = nullptr;
     // first-hit image of the last call (vp_copy_hit_image)
     bool has_hit = false;
@@ -184,7 +186,8 @@ bool sticky_open(WsState &st)
 {
     if (st.sticky_host) return true;
     void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, 256, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // (coherent = fine-grained: a blocking one-view call polls ST_HOST_NSPLIT while its gather runs)
+    if (hipHostMalloc(&h, 256, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
     memset(h, 0, 256);      // ST_WORDS ints (the enum follows below)
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
     st.sticky_host = (int *)h;
@@ -233,11 +236,14 @@ struct Params {
 // of the tables it holds (0 while none are sealed) -- written by k_ws_open / k_ws_seal, compared by every call's k_zero_call.
 enum { ST_BADID = 0, ST_BOXMISS = 1, ST_NHEAVY = 2, ST_ZERO = 3 /* never written */, ST_STUCK = 4, ST_OCCDIFF = 5, ST_STALE = 6,
        ST_HEAVY_T = 7,                         // per-call: the heavy threshold in force (after the part-slot bound), for the counters
+       ST_NHIT = 8,                            // per-call: pixels whose ray hit a voxel (one-view calls that size their parts from it: k_worklist's sum of the march's per-wavefront counts)
+       ST_PART_T = 9, ST_PART_PX = 10,         // per-call: pixels above which a voxel was cut into parts, pixels per part (k_worklist)
        ST_WORK0 = 16, WORK_CLASSES = 8,        // per-call: number of voxels in each size class of the gather's work list
        ST_NPARTS = 24, ST_NSPLIT = 25,         // per-call, next to the class counts: parts and split voxels planned by k_worklist
        ST_PLAN_WORDS = WORK_CLASSES + 2,       // ST_WORK0 .. ST_NSPLIT: what a work-list run (re)counts
        ST_CALL_WORDS = 32,
        ST_HDR_MAGIC = 56, ST_HDR_GEN = 57, ST_HDR_TABLES = 58,
+       ST_HOST_NSPLIT = 60,                    // sticky page only: k_gather_one's note to a blocking one-view call (GatherArgs::host_word)
        ST_STICKY_STALE = 61, ST_STICKY_BADID = 62, ST_STICKY_STUCK = 63, ST_WORDS = 64 };
 constexpr unsigned WS_MAGIC = 0x56585033u;   // "VXP3"
 #ifdef VP_DIAG
@@ -283,6 +289,8 @@ struct Layout {
     size_t occ_copy;                                     // (int)occupancy the tables were built from (VP_FLAG_VERIFY_ACCEL)
     size_t status[2], cnt_call[2], heavy[2], work[2], viewtab[2], hit[2];   // per-call buffers, two sets (VP_FLAG_PIPELINE)
     size_t parts[2], split[2], pmeta[2], prow[2];        // split voxels (vp_gather.h): part items, split list, per-part results
+    size_t hitcnt[2];                                    // one-view calls: hit pixels per wavefront of the march (k_worklist adds them up)
+    long long n_hitcnt;
     long long slot_cap;                                  // part slots per set
     size_t total;
     int nbx, nby, nbz;
@@ -307,10 +315,9 @@ inline long long part_slot_cap(int B, int V, int H, int W, int C)
     const long long px2 = 2ll * B * V * (long long)H * W;
     const long long by_bytes = std::max<long long>(1024, ((long long)VP_MAX_SLOTS * 2048) / (std::max(C, 1) * 4ll));
     long long cap = std::max<long long>(64, std::min<long long>(VP_MAX_SLOTS, std::min(px2, by_bytes)));
-    // a call of ONE view cuts voxels into parts only through the general gather kernel (VP_OPT_ONE_VIEW_GATHER = 0, the A/B arm),
-    // with parts of 320 pixels by default: 4096 slots (8 MiB at C = 512) cover a view of 650 k pixels -- the drop-in module's
-    // scratch buffer should not carry 2 x 64 MiB it never touches
-    if ((long long)B * V == 1) cap = std::min<long long>(cap, 4096);
+    // a call of ONE view cuts voxels into parts of 256 pixels by default (128 at the least for a view of 524 k pixels): 8192 slots
+    // (16 MiB at C = 512) -- the drop-in module's scratch buffer should not carry 2 x 64 MiB it never touches
+    if ((long long)B * V == 1) cap = std::min<long long>(cap, 8192);
     return cap;
 }
 
@@ -337,7 +344,10 @@ Layout make_layout(int B, int V, int H, int W, int C, long long n_rows, int dimz
     l.slot_cap = part_slot_cap(B, V, H, W, C);
     const size_t sz_view = align256(size_t(B) * V * sizeof(ViewEntry)), sz_hit = align256(size_t(B) * V * H * W * sizeof(int));
     const size_t sz_i4 = align256(size_t(l.slot_cap) * 16), sz_prow = align256(size_t(l.slot_cap) * size_t(C) * sizeof(float));
-    const size_t per_set = sz_view + sz_hit + 3 * sz_i4 + sz_prow;
+    // one int per wavefront (8x8 pixel tile) of a ONE-VIEW march: the view's hit total sizes its parts (PlanArgs, vp_gather.h)
+    l.n_hitcnt = (long long)B * V == 1 ? (long long)((W + 15) / 16) * ((H + 15) / 16) * 4 : 0;
+    const size_t sz_hc = align256(size_t(l.n_hitcnt) * sizeof(int));
+    const size_t per_set = sz_view + sz_hit + 3 * sz_i4 + sz_prow + sz_hc;
     size_t half = per_set;
     if (capacity > off + 2 * per_set) half = ((capacity - off) / 2) & ~size_t(255);
     for (int q = 0; q < 2; q++) {
@@ -347,6 +357,7 @@ Layout make_layout(int B, int V, int H, int W, int C, long long n_rows, int dimz
         l.split[q] = l.parts[q] + sz_i4;
         l.pmeta[q] = l.split[q] + sz_i4;
         l.prow[q] = l.pmeta[q] + sz_i4;
+        l.hitcnt[q] = l.prow[q] + sz_prow;
     }
     l.total = off + 2 * per_set;
     return l;

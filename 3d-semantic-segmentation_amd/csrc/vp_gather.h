@@ -221,7 +221,10 @@ struct GatherArgs {
     const int *cnt_call;
     const int *heavy_list;   // one-view calls: IDs whose pixel count exceeds heavy_t (appended by phase 1)
     const int *n_heavy;
-    int heavy_t;
+    int parts_on;            // k_gather_one: the call's work list has part items (one-view calls that split large voxels)
+    int *host_word;          // nullable (blocking one-view calls): pinned host word that receives "split voxels of this call" when the
+    int host_seq;            // gather starts, tagged with the call's sequence number -- the host then launches k_combine_parts only if any
+    int slot_cap;            // part slots of the buffer set: the consumers never walk past it, whatever the counters say
     int row_lo, row_hi;      // phase 2 of this launch covers the voxel IDs in [row_lo, row_hi) (VP_OPT_ROW_BEGIN / _END)
     int heavy_blocks;        // k_gather_one: leading workgroups that take the view's heavy voxels
     const int *work;         // work list of this call: WORK_CLASSES arrays of n_rows voxel IDs, by size class (k_worklist)
@@ -239,6 +242,34 @@ struct GatherArgs {
 constexpr int GW_MERGED = 4;     // wavefronts that share one heavy voxel inside k_gather_one (= one of its workgroups)
 constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather_one that take the view's heavy voxels
 constexpr int COMBINE_BLOCKS = 512; // grid of k_combine_parts (a workgroup per split voxel at a time)
+// One-view calls size their parts on the device, from the number of pixels the view's rays hit (k_worklist): the smallest part,
+// and how many parts' worth of pixels a voxel must exceed to be cut (VP_OPT_PART_PIXELS / VP_OPT_ONE_VIEW_SPLIT fix them)
+#ifndef VP_ONE_VIEW_PART_MIN
+#define VP_ONE_VIEW_PART_MIN 32
+#endif
+#ifndef VP_ONE_VIEW_T_RATIO
+#define VP_ONE_VIEW_T_RATIO 2
+#endif
+#ifndef VP_ONE_VIEW_T_FLOOR_SMALL
+#define VP_ONE_VIEW_T_FLOOR_SMALL 256
+#endif
+constexpr int ONE_VIEW_PART_MIN = VP_ONE_VIEW_PART_MIN, ONE_VIEW_T_RATIO = VP_ONE_VIEW_T_RATIO, ONE_VIEW_T_FLOOR_SMALL = VP_ONE_VIEW_T_FLOOR_SMALL;
+
+// What k_worklist plans with.  Calls of more than one view: heavy_t == part_t and part_px are the host's (project_impl).
+// One-view calls that split (round 6): no voxel is shared by a workgroup any more, heavy_t == part_t again, and both numbers may
+// be left to the device: dyn_px_min > 0 -> part_px = max(dyn_px_min, 2 * hits / slots), with `hits` the pixels of the view whose
+// ray hit a voxel (counted by the march, ST_NHIT) -- about one part per wavefront the machine holds on a frame that is all large
+// voxels, parts of 32 pixels on a frame that is mostly misses, where the longest single item IS the launch (a wavefront alone
+// pulls ~5 GB/s: 320 rows of 2 KiB last 128 us); dyn_t_ratio > 0 -> part_t = heavy_t = max(dyn_t_ratio * part_px, dyn_t_floor): a
+// voxel is worth cutting only when one wavefront would need a good part of the launch's duration for it -- ~26 us are 64 pixels
+// with 4 rows in flight per wavefront, and views of up to 262144 pixels (8 rows in flight; a quarter-resolution frame is ten
+// thousand voxels of a dozen pixels, bounded by round trips per voxel, not by its longest voxel) gain nothing below 256.
+struct PlanArgs {
+    int heavy_t, part_t, part_px;
+    int count_heavy;      // add the split voxels to ST_NHEAVY (0: the march counts the voxels above heavy_t, one-view calls without parts)
+    int dyn_px_min, dyn_t_ratio, dyn_t_floor;
+    int cell_in_item;     // parts[].w = the voxel's cell in batch 0 instead of its first slot (one-view calls: B == 1)
+};
 
 // Views whose first ID tile is fetched together by the one-wavefront gather (template argument G of k_gather; 1 = one view
 // at a time).  fp16 rows: 4 (-1 % pipelined, round 2).  fp32 rows: 4 for small images (a voxel of R1's 484x274 views gathers
@@ -570,6 +601,46 @@ __device__ __forceinline__ void gather_part_wave(const GatherArgs &g, const Para
     if (lane == 0) g.pmeta[slot] = make_int4(found0, nviews, first_v, last_v);
 }
 
+// A part of a ONE-VIEW call (B*V == 1): the same cut as gather_part_wave makes for one view -- part k of P owns the box rows whose
+// first pixel's area index lies in [A k / P, A (k+1) / P) --, with the box computed once, by every lane alike, from the cell
+// k_worklist left in the item (one dependent load fewer in front of the first row).  No cell or no box: the part finds nothing and
+// k_combine_parts redoes the voxel over the whole image.
+template <int K, int VEC, int U>
+__device__ __forceinline__ void gather_part_one(const GatherArgs &g, const Params &p, int slot, int lane)
+{
+    const int4 it = g.parts[slot];
+    const int id = it.x, part = it.y, P = it.z, cell = it.w;
+    const int W = p.width, H = p.height, C = p.C;
+    constexpr int CB = 64 * K * VEC;
+    int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+    if (cell >= 0) {
+        const int czi = cell / (p.dimy * p.dimx);
+        const int rem = cell - czi * (p.dimy * p.dimx);
+        const int cyi = rem / p.dimx, cxi = rem - cyi * p.dimx;
+        int a0, a1, a2, a3;
+        if (voxel_box(g.viewtab[0], g.intr[0], g.intr[1], g.intr[2], g.intr[3], p.ox + (float)cxi * p.vs, p.oy + (float)cyi * p.vs,
+                      p.oz + (float)czi * p.vs, box_half_edge(p), near_plane(p), W, H, a0, a1, a2, a3)) { x0 = a0; y0 = a1; x1 = a2; y1 = a3; }
+    }
+    const long long bw = x1 - x0 + 1, bh = y1 - y0 + 1, A = bw * bh;
+    int r_lo = 0, r_hi = 0;
+    if (A > 0) {
+        const long long lo = A * part / P, hi = A * (part + 1) / P;
+        r_lo = (int)((lo + bw - 1) / bw);
+        r_hi = hi < A ? (int)((hi + bw - 1) / bw) : (int)bh;
+    }
+    int found0 = 0;
+    for (int cb = 0; cb < C; cb += CB) {
+        Acc<K, VEC> acc;
+#pragma unroll
+        for (int i = 0; i < K * VEC; i++) acc.a[i] = 0.f;
+        int found = 0;
+        if (r_lo < r_hi) scan_box<K, VEC, U>(g.feats, g.hit, W, C, id, x0, y0 + r_lo, x1, y0 + r_hi - 1, cb, lane, acc, found);
+        acc_store<K, VEC, false>(acc, g.prow + (long long)slot * C + cb, cb, C, lane);
+        if (cb == 0) found0 = found;
+    }
+    if (lane == 0) g.pmeta[slot] = make_int4(found0, found0 > 0 ? 1 : 0, found0 > 0 ? 0 : -1, found0 > 0 ? 0 : -1);
+}
+
 // Heavy role (the first HEAVY_BLOCKS workgroups of k_gather_one): the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
 // in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
 // each wavefront sums its range in raster order, and the partial rows are combined through LDS in
@@ -679,16 +750,19 @@ __device__ bool gather_voxel_block(const GatherArgs &g, const Params &p, int id,
 constexpr int WL_PER_THREAD = 16;   // IDs per lane of k_worklist: a 256-thread workgroup bins 4096 voxel IDs
 
 // [row_lo, row_hi): the IDs this call's phase 2 gathers (VP_OPT_ROW_BEGIN / _END; [1, n_rows) when no range is set).
-// part_px > 0: the launch also PLANS the split voxels (see "Split voxels" above): a voxel with more than heavy_t pixels
+// part_px > 0: the launch also PLANS the split voxels (see "Split voxels" above): a voxel with more than part_t pixels
 // gets P = ceil(c / part_px) consecutive part slots and an entry in the split list; slots and entries are handed out per
-// workgroup (LDS counters, two global atomics per workgroup).  The host chose part_px and heavy_t such that the parts of a
-// call cannot outnumber slot_cap (project_impl); the guard below only keeps a broken promise from writing out of bounds.
-// part_px == 0 (one-view calls): the voxels above heavy_t are in the march's heavy list and stay out of this list.
-__global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, int heavy_t, int part_px, long long n_rows,
+// workgroup (LDS counters, two global atomics per workgroup).  part_px and part_t >= part_px are such that the parts of a
+// call cannot outnumber slot_cap (project_impl; PlanArgs for the numbers derived here); the guard below only keeps a broken
+// promise from writing out of bounds, and the consumers clamp what they walk to slot_cap.
+// One-view calls without parts (VP_OPT_ONE_VIEW_SPLIT = 0): the voxels above heavy_t are in the march's heavy list (a workgroup
+// of k_gather_one sums each) and stay out of this list, ST_NHEAVY is the march's count.  part_px == 0: nothing is split.
+__global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_call, PlanArgs plan, long long n_rows,
                                                   int *__restrict__ work, int *status, int wl_blocks,
                                                   const float *__restrict__ vmi, ViewEntry *viewtab, int n_views,
                                                   long long row_lo, long long row_hi, int4 *__restrict__ parts,
-                                                  int4 *__restrict__ split, int slot_cap, int *sticky)
+                                                  int4 *__restrict__ split, int slot_cap, int *sticky,
+                                                  const int *__restrict__ cell_of_id, const int *__restrict__ hit_waves, int n_hit_waves)
 {
     if ((int)blockIdx.x >= wl_blocks) {
         // trailing workgroups: the call's view table (phase 2's world->camera maps), one thread per view -- riding on
@@ -697,29 +771,61 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
         if (v < n_views) view_entry(vmi, viewtab, v);
         return;
     }
-    int *work_n = status + ST_WORK0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_HEAVY_T] = heavy_t;
-    // Appends are aggregated per WORKGROUP through LDS: a handful of global atomics per 4096 IDs.  (Returning integer
-    // atomics on a few hot addresses are exactly what slows a concurrently running gather -- DESIGN.md section 2.)
-    // Counters WORK_CLASSES and WORK_CLASSES + 1: part slots and split voxels.
-    __shared__ int n_cls[WORK_CLASSES + 2], base_cls[WORK_CLASSES + 2], n_split2;
-    if (threadIdx.x < WORK_CLASSES + 2) n_cls[threadIdx.x] = 0;
-    if (threadIdx.x == 0) n_split2 = 0;
-    __syncthreads();
+    int heavy_t = plan.heavy_t, part_t = plan.part_t, part_px = plan.part_px;
+    __shared__ int n_cls[WORK_CLASSES + 2], base_cls[WORK_CLASSES + 2], n_split2, hits_lds;
+    // this workgroup's 4096 pixel counts: requested first, so that they travel together with the loads of the hit total below
+    // (the launch is a chain of dependent round trips -- counts, the classes' global bases, the list entries -- of 1.5 us each)
     const long long id0 = (long long)blockIdx.x * (256 * WL_PER_THREAD);
-    int cls[WL_PER_THREAD], rank[WL_PER_THREAD];
+    int cv[WL_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < WL_PER_THREAD; j++) {
         // consecutive lanes take consecutive IDs, so the ranks inside a class follow the ID order closely
         const long long id = id0 + (long long)j * 256 + threadIdx.x;
-        int c = 0;
-        if (id >= row_lo && id < row_hi) c = cnt_call[id];
+        cv[j] = (id >= row_lo && id < row_hi) ? cnt_call[id] : 0;
+    }
+    if (plan.dyn_px_min > 0) {
+        // the march has finished: every workgroup adds up its per-wavefront hit counts (a few thousand ints from L2) -- no
+        // atomic on one hot word in the march, no second launch.  2 * hits / part_px <= slot_cap bounds the parts (see above)
+        if (threadIdx.x == 0) hits_lds = 0;
+        __syncthreads();
+        // (16 ints per thread and round, all four loads in flight: one dependent load per round was 5 us of this launch)
+        int mine = 0;
+        const int4 *hw4 = reinterpret_cast<const int4 *>(hit_waves);      // 256-byte aligned, a multiple of four ints
+        const int n4 = n_hit_waves >> 2;
+        for (int j = threadIdx.x; j < n4; j += 1024) {
+            int4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[u] = j + u * 256 < n4 ? hw4[j + u * 256] : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) mine += a[u].x + a[u].y + a[u].z + a[u].w;
+        }
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&hits_lds, mine);
+        __syncthreads();
+        const long long hits = hits_lds;
+        if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_NHIT] = (int)hits;
+        part_px = (int)max((long long)max(part_px, plan.dyn_px_min), (2 * hits + slot_cap - 1) / slot_cap);
+    }
+    if (plan.dyn_t_ratio > 0) heavy_t = part_t = (int)min(max((long long)part_px * plan.dyn_t_ratio, (long long)plan.dyn_t_floor), 2147483646ll);
+    if (part_px > 0 && part_t < part_px) { part_t = part_px; heavy_t = max(heavy_t, part_t); }
+    int *work_n = status + ST_WORK0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { status[ST_HEAVY_T] = heavy_t; status[ST_PART_T] = part_t; status[ST_PART_PX] = part_px; }
+    // Appends are aggregated per WORKGROUP through LDS: a handful of global atomics per 4096 IDs.  (Returning integer
+    // atomics on a few hot addresses are exactly what slows a concurrently running gather -- DESIGN.md section 2.)
+    // Counters WORK_CLASSES and WORK_CLASSES + 1: part slots and split voxels.
+    if (threadIdx.x < WORK_CLASSES + 2) n_cls[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_split2 = 0;
+    __syncthreads();
+    int cls[WL_PER_THREAD], rank[WL_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < WL_PER_THREAD; j++) {
+        const int c = cv[j];
         cls[j] = -1;
         rank[j] = 0;
         if (c > 0 && c <= heavy_t) {
             cls[j] = min(WORK_CLASSES - 1, max(0, 28 - __builtin_clz(c)));     // floor(log2 c) - 3
             rank[j] = atomicAdd(&n_cls[cls[j]], 1);
-        } else if (c > heavy_t && part_px > 0) {
+        } else if (c > part_t && part_px > 0) {
             cls[j] = WORK_CLASSES;
             rank[j] = atomicAdd(&n_cls[WORK_CLASSES], (c + part_px - 1) / part_px);
             atomicAdd(&n_cls[WORK_CLASSES + 1], 1);
@@ -729,7 +835,7 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
     if (threadIdx.x < WORK_CLASSES + 2) {
         const int n = n_cls[threadIdx.x];
         base_cls[threadIdx.x] = n > 0 ? atomicAdd(&work_n[threadIdx.x], n) : 0;
-        if (threadIdx.x == WORK_CLASSES + 1 && n > 0) atomicAdd(&status[ST_NHEAVY], n);      // the counter tests and the bench read
+        if (threadIdx.x == WORK_CLASSES + 1 && n > 0 && plan.count_heavy) atomicAdd(&status[ST_NHEAVY], n);      // the counter tests and the bench read
     }
     __syncthreads();
 #pragma unroll
@@ -738,7 +844,7 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
         if (cls[j] >= 0 && cls[j] < WORK_CLASSES) {
             work[(long long)cls[j] * n_rows + base_cls[cls[j]] + rank[j]] = id;
         } else if (cls[j] == WORK_CLASSES) {
-            const int c = cnt_call[id];
+            const int c = cv[j];
             const int P = (c + part_px - 1) / part_px;
             const int base = base_cls[WORK_CLASSES] + rank[j];
             const int sidx = base_cls[WORK_CLASSES + 1] + atomicAdd(&n_split2, 1);
@@ -748,7 +854,8 @@ __global__ __launch_bounds__(256) void k_worklist(const int *__restrict__ cnt_ca
                 continue;
             }
             split[sidx] = make_int4(id, base, P, c);
-            for (int q = 0; q < P; q++) parts[base + q] = make_int4(id, q, P, base);
+            const int w4 = plan.cell_in_item ? cell_of_id[id] : base;
+            for (int q = 0; q < P; q++) parts[base + q] = make_int4(id, q, P, w4);
         }
     }
 }
@@ -769,7 +876,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g, Params p)
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_parts = g.work_n[WORK_CLASSES];
+    const int n_parts = min(g.work_n[WORK_CLASSES], g.slot_cap);
     if (w < n_parts) {
         gather_part_wave<K, VEC, U>(g, p, (int)w, lane);
         return;
@@ -799,7 +906,7 @@ __global__ __launch_bounds__(256) void k_combine_parts(GatherArgs g, Params p)
     __shared__ __attribute__((aligned(16))) float part[GW_MERGED][64 * K * VEC];
     __shared__ int part_found[GW_MERGED];
     __shared__ int meta[GW_MERGED][4];
-    const int n_split = g.work_n[WORK_CLASSES + 1];
+    const int n_split = min(g.work_n[WORK_CLASSES + 1], g.slot_cap);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, tid = threadIdx.x;
     const int C = p.C;
     constexpr int CB = 64 * K * VEC;
@@ -807,6 +914,7 @@ __global__ __launch_bounds__(256) void k_combine_parts(GatherArgs g, Params p)
     for (int j = blockIdx.x; j < n_split; j += gridDim.x) {
         const int4 sp = g.split[j];
         const int id = sp.x, base = sp.y, P = sp.z, expected = sp.w;
+        if (base < 0 || P <= 0 || (long long)base + P > g.slot_cap) continue;      // never written by k_worklist (its guard fired: ST_BADID is up)
         const int q0 = (int)((long long)P * w / GW_MERGED), q1 = (int)((long long)P * (w + 1) / GW_MERGED);
         {   // this wavefront's run of slots: pixels found, distinct views, first and last contributing view
             int f = 0, nv = 0, first = -1, last = -1;
@@ -934,6 +1042,19 @@ __global__ __launch_bounds__(256) void k_gather_one(GatherArgs g, Params p)
     const int lane = threadIdx.x & 63;
     const long long NW = (long long)gridDim.x * 4;
     const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Parts of the view's split voxels (round 6) lead the deal -- they are its longest items: the items of the launch are the
+    // n_parts parts, then the size-ordered list; wavefront w takes the items w, w + NW, w + 2 NW, ...  One wavefront per part, into
+    // the part's slot; k_combine_parts follows on the stream.
+    long long first = w;      // this wavefront's first entry of the list
+    if (g.host_word && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(g.host_word, (int)(0x80000000u | ((unsigned)g.host_seq << 16) | (unsigned)min(g.work_n[WORK_CLASSES + 1], 0xffff)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (g.parts_on) {
+        const long long n_parts = min(g.work_n[WORK_CLASSES], g.slot_cap);
+        long long s = w;
+        for (; s < n_parts; s += NW) gather_part_one<K, VEC, U>(g, p, (int)s, lane);
+        first = s - n_parts;
+    }
     int n[WORK_CLASSES];
     long long total = 0;
 #pragma unroll
@@ -942,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_gather_one(GatherArgs g, Params p)
     constexpr int CB = 64 * K * VEC;
     const float *fv = g.feats;
     const int *hv = g.hit;
-    for (long long base = w; base < total; base += 64 * NW) {
+    for (long long base = first; base < total; base += 64 * NW) {
         // lane j: the j-th entry of this wavefront in this batch -- ID, box, pixel count
         long long r = base + (long long)lane * NW;
         int id_l = 0;

@@ -44,6 +44,8 @@ struct FirstHitArgs {
     int *cnt_call;
     int *heavy_list;
     int heavy_t;
+    int *hit_waves; // nullable: [wavefront of the grid] = pixels of its tile whose ray hit a voxel (one-view calls that size their
+                    // parts from the total; a plain store per wavefront -- one atomic word for all of them cost the march 85 us)
     int *status;
     int *sticky;   // the workspace record's sticky error words (pinned host memory, device mapping; never cleared by a call)
 };
@@ -308,6 +310,8 @@ __device__ __forceinline__ void first_hit_body(const FirstHitArgs &fa, const Par
         const int lane_ = threadIdx.x & 63;
         int my_n = 0;
         unsigned long long todo = __ballot(id != 0);
+        if (fa.hit_waves && todo != 0ull && lane_ == __builtin_ctzll(todo))
+            fa.hit_waves[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = __popcll(todo);
         while (todo) {
             const int l = __builtin_ctzll(todo);
             const int cur = __builtin_amdgcn_readlane(id, l);

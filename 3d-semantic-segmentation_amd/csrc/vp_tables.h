@@ -187,9 +187,12 @@ __global__ void k_ws_seal(int *status0, unsigned tables) { status0[ST_HDR_TABLES
 // stale: k_first_hit then does nothing (so neither does the gather: the histogram stays zero) and the sticky word makes
 // vp_workspace_status report it.
 __global__ __launch_bounds__(256) void k_zero_call(int *__restrict__ status, int *__restrict__ cnt_call, long long n_rows,
-                                                   int *hdr, int *sticky, unsigned magic, unsigned gen, unsigned tables)
+                                                   int *hdr, int *sticky, unsigned magic, unsigned gen, unsigned tables,
+                                                   int *__restrict__ hit_waves, long long n_hit_waves)
 {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    // the march's per-wavefront hit counts (one-view calls): wavefronts whose tile lies outside the image never write theirs
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_hit_waves; j += (long long)gridDim.x * blockDim.x) hit_waves[j] = 0;
     if (blockIdx.x == 0 && threadIdx.x < ST_CALL_WORDS) {
         int v = 0;
         if (threadIdx.x == ST_STALE) {

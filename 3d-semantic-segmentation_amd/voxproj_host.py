@@ -52,13 +52,14 @@ EXPORTS = [
     "vp_upsample_workspace_bytes", "vp_upsample_features", "vp_voxel_coords", "vp_scatter_occupancy",
     "vp_aggregate_view_f16", "vp_workspace_create", "vp_workspace_set_option",
 ]
-VP_ABI_VERSION = 3
+VP_ABI_VERSION = 4
 VP_OPT_HEAVY_THRESHOLD = 1
 VP_OPT_MARCH_LDS_KB = 2
 VP_OPT_ROW_BEGIN = 3
 VP_OPT_ROW_END = 4
 VP_OPT_ONE_VIEW_GATHER = 5
 VP_OPT_PART_PIXELS = 6
+VP_OPT_ONE_VIEW_SPLIT = 7
 
 
 class VoxprojError(RuntimeError):
@@ -211,7 +212,7 @@ class Workspace:
         if self.buf is None or self._applied == state:
             return
         merged = {VP_OPT_HEAVY_THRESHOLD: -1, VP_OPT_MARCH_LDS_KB: -1, VP_OPT_ROW_BEGIN: -1, VP_OPT_ROW_END: -1, VP_OPT_ONE_VIEW_GATHER: -1,
-                  VP_OPT_PART_PIXELS: -1}
+                  VP_OPT_PART_PIXELS: -1, VP_OPT_ONE_VIEW_SPLIT: -1}
         merged.update(_default_options)
         merged.update(self.options)
         for opt, val in merged.items():
@@ -380,15 +381,18 @@ def hit_image(ws, device):
 
 
 def counters(ws, device):
-    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss, n_heavy, heavy_t, n_parts) -- n_heavy = voxels
-    above the heavy threshold in force (heavy_t: the option or min(256 + 64*B*V, 2048), raised to the part-slot bound where that binds),
-    n_parts = the parts they were cut into (0 for one-view calls, whose heavy voxels a workgroup sums)."""
+    """Device-side diagnostic counters of the last call: dict(bad_id, box_miss, n_heavy, heavy_t, n_parts, n_split) -- n_heavy = voxels
+    above the heavy threshold in force (heavy_t: the option or min(256 + 64*B*V, 2048), raised to the part-slot bound where that binds;
+    one-view calls: the device's choice, see below), n_split = the voxels cut into parts, n_parts = their parts; part_t / part_px =
+    pixels above which a voxel was cut and pixels per part; n_hit = pixels whose ray hit a voxel (counted only by one-view calls
+    that size their parts from it: part_px = max(32, 2 * n_hit / slots), part_t = heavy_t = 2 * part_px)."""
     import torch
     arr = (ctypes.c_int32 * 32)()
     ptr = ws.ptr()
     stream = torch.cuda.current_stream(device).cuda_stream
     check(lib().vp_workspace_counters(ptr, arr, 32, stream))
-    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]), n_heavy=int(arr[2]), heavy_t=int(arr[7]), n_parts=int(arr[24]))
+    return dict(bad_id=int(arr[0]), box_miss=int(arr[1]), n_heavy=int(arr[2]), heavy_t=int(arr[7]), n_parts=int(arr[24]), n_split=int(arr[25]),
+                n_hit=int(arr[8]), part_t=int(arr[9]), part_px=int(arr[10]))
 
 
 def table_builds(ws):

@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 3   /* additions since 3 that old callers never see: VP_FLAG_GATHER_ONLY, VP_OPT_ROW_BEGIN / _END */
+#define VP_ABI_VERSION 4   /* 4: the workspace carries part slots for split voxels (vp_workspace_bytes grew), vp_profile_read slot [3]
+                              is k_combine_parts, counters [7] / [24] / [25], VP_OPT_PART_PIXELS, VP_OPT_ONE_VIEW_SPLIT; one-view calls
+                              split large voxels too.  A caller built against 3 must re-query vp_workspace_bytes */
 
 enum {
     VP_OK = 0,
@@ -180,8 +182,8 @@ int vp_workspace_status(void *workspace, void *stream);
  * stream synchronise: [0] = rays that hit an out-of-range ID, [1] = voxels whose search box
  * missed pixels and were rescanned over whole images (performance hint only; results are exact
  * either way), [2] = voxels that collected more pixels than the heavy threshold in this call (summed in
- * parts; one-view calls: by a whole workgroup), [7] = the heavy threshold in force, [24] = the parts those
- * voxels were cut into.  No reference counterpart.
+ * parts; one-view calls: by a whole workgroup up to VP_OPT_ONE_VIEW_SPLIT pixels, in parts above), [7] = the heavy
+ * threshold in force, [24] = the parts planned in this call, [25] = the voxels they belong to.  No reference counterpart.
  */
 int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream);
 
@@ -192,7 +194,7 @@ int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *str
  * vp_profile_read synchronises the recorded events and returns, per kernel group, the summed
  * milliseconds and the number of launches: [0] = table preparation (memsets, occupancy tables, view
  * table), [1] = k_first_hit + work list + view table (phase 1), [2] = k_gather / k_gather_one (phase 2, the parts of the split
- * voxels included), [3] = k_combine_parts (the split voxels' partial rows added to their rows; calls of more than one view);
+ * voxels included), [3] = k_combine_parts (the split voxels' partial rows added to their rows);
  * then clears the record.
  */
 int vp_profile_enable(int on);
@@ -295,9 +297,13 @@ int vp_workspace_release(void *workspace);
  *                           ONE view: shared by the four wavefronts of a workgroup).  Default min(256 + 64*B*V, 2048) -- the
  *                           longest job a wavefront can get bounds the tail of the launch --, 320 for calls of one view;
  *                           VP_FLAG_SERIAL_SUMS overrides it with "never".  Never below the part size
- *   VP_OPT_PART_PIXELS      pixels per part of a split voxel (default: the threshold); raised to 2*B*V*H*W / slots when the call
- *                           is so large that its parts could outnumber the workspace's part slots (32768, fewer for rows wider
- *                           than 2 KiB)
+ *   VP_OPT_PART_PIXELS      pixels per part of a split voxel (default: the threshold; 256 for calls of one view); raised to
+ *                           2*B*V*H*W / slots when the call is so large that its parts could outnumber the workspace's part
+ *                           slots (32768, fewer for rows wider than 2 KiB; 8192 for calls of one view)
+ *   VP_OPT_ONE_VIEW_SPLIT   calls of ONE view: voxels that collect more than this many pixels are cut into parts like those of
+ *                           multi-view calls (one wavefront of the one-view gather per part, k_combine_parts behind it); the
+ *                           voxels between VP_OPT_HEAVY_THRESHOLD and this value keep the workgroup role.  Default 1024;
+ *                           0 = never split (round 5's behaviour, the A/B arm); never below the part size
  *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
  *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a
  *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise).  Valid: 0 .. 64
@@ -312,7 +318,7 @@ int vp_workspace_release(void *workspace);
  *                           (default 16; 1000 + g: exactly g workgroups, a test hook); < 0 restores the default
  */
 enum { VP_OPT_HEAVY_THRESHOLD = 1, VP_OPT_MARCH_LDS_KB = 2, VP_OPT_ROW_BEGIN = 3, VP_OPT_ROW_END = 4, VP_OPT_ONE_VIEW_GATHER = 5,
-       VP_OPT_PART_PIXELS = 6 };
+       VP_OPT_PART_PIXELS = 6, VP_OPT_ONE_VIEW_SPLIT = 7 };
 int vp_workspace_set_option(void *workspace, int option, long long value);
 
 /* How many times the occupancy-derived tables of this workspace have been (re)built so far (0 if never);

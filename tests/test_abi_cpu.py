@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(voxproj_host.EXPORTS) == names
     lib.vp_abi_version.restype = ctypes.c_int
-    assert lib.vp_abi_version() == 3
+    assert lib.vp_abi_version() == 4
 
 
 def test_workspace_record_calls_validate_their_arguments_on_the_host():

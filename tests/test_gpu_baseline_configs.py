@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 import torch
 
+from sum_criteria import abs_sums_from_hits, assert_sums
 from synthetic_scene import make_features_torch, make_scene
 
 pytestmark = pytest.mark.gpu
@@ -81,13 +82,9 @@ def _feature_config(oracle_mod, n_vox, n_views_scene, W, H, C, views, min_heavy)
     assert got[light].tobytes() == out[light].tobytes(), "one-wavefront rows must equal the oracle's serial fp32 sums"
     if not heavy.any():
         return dict(rel_row=0.0, n_heavy=0, hit_frac=float((r["hits"] > 0).mean()))
-    ref64 = r["out64"][heavy]
-    err = np.abs(got[heavy].astype(np.float64) - ref64)
-    row_mag = np.abs(ref64).max(axis=1, keepdims=True)
-    assert (err <= 1e-4 * row_mag).all(), float((err / row_mag).max())
-    solid = np.abs(ref64) >= 1e-2 * row_mag
-    assert (err[solid] <= 1e-4 * np.abs(ref64)[solid]).all(), float((err[solid] / np.abs(ref64)[solid]).max())
-    return dict(rel_row=float((err / row_mag).max()), n_heavy=int(heavy.sum()), hit_frac=float((r["hits"] > 0).mean()))
+    _, abs64 = abs_sums_from_hits(r["hits"][0], feats_t[0], n_rows, dev)
+    res = assert_sums(out_t, r["out64"], abs64, count, split=heavy, oracle32=out, dev=dev)      # tests/sum_criteria.py
+    return dict(rel_row=res["rel_row"], n_heavy=int(heavy.sum()), hit_frac=float((r["hits"] > 0).mean()))
 
 
 def test_config2_r1_shape_four_views_vs_oracle(oracle_mod):
@@ -229,6 +226,7 @@ def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
     assert len(views) == V and ctr["n_heavy"] == max(heavy_per_call) > 0, heavy_per_call
     # the reference: oracle march -> float64 scatter-add on the device, view by view
     ref = torch.zeros(n_rows, C, dtype=torch.float64, device=dev)
+    ref_abs = torch.zeros(n_rows, C, dtype=torch.float64, device=dev)
     count_ref = np.zeros(n_rows, np.int64)
     views_ref = np.zeros(n_rows, np.int64)
     sub = 20
@@ -242,6 +240,7 @@ def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
             ids = torch.from_numpy(hits[0, v].reshape(-1).astype(np.int64)).to(dev)
             rows = feats[0, a + v].reshape(-1, C).double()
             ref.index_add_(0, ids, rows)
+            ref_abs.index_add_(0, ids, rows.abs())
             del rows
     count_ref[0] = 0
     got_c = count_t.cpu().numpy().astype(np.int64)
@@ -251,14 +250,6 @@ def test_config3_one_bench_sized_call_rows_vs_float64_reference(oracle_mod):
     heavy = torch.from_numpy(count_ref > heavy_t).to(dev)
     assert ctr["n_heavy"] == int(heavy.sum().item()) > 0 and int(count_ref.max()) > heavy_t
     ref[0] = 0
-    err = (out_t.double() - ref).abs()
-    row_mag = ref.abs().max(dim=1, keepdim=True).values
-    touched = torch.from_numpy(count_ref > 0).to(dev)
-    assert float(out_t[~touched].abs().max().item()) == 0.0                 # untouched rows stay untouched
-    rel_row = (err[touched] / row_mag[touched])
-    assert float(rel_row.max().item()) <= 1e-4, float(rel_row.max().item())
-    solid = touched[:, None] & (ref.abs() >= 1e-2 * row_mag)
-    rel_el = err[solid] / ref.abs()[solid]
-    assert float(rel_el.max().item()) <= 1e-4, float(rel_el.max().item())
-    # and the split rows on their own (parts combined in slot order)
-    assert float((err[heavy] / row_mag[heavy]).max().item()) <= 1e-4
+    ref_abs[0] = 0
+    res = assert_sums(out_t, ref, ref_abs, count_ref, dev=dev)      # tests/sum_criteria.py: every element of every row
+    print(f"config 3, one bench-sized call: sum criterion {res}")

@@ -78,9 +78,10 @@ def test_one_view_calls_match_the_oracle_and_the_general_kernel(oracle_mod, C, h
 
 
 def test_one_view_heavy_voxels_take_the_workgroup_role_of_the_same_launch(oracle_mod):
-    """Threshold 6 pixels: most voxels of the view are "heavy" and go to the first workgroups of k_gather_one (four wavefronts
+    """Round 5's path for the large voxels of a one-view call, kept as the A/B arm (VP_OPT_ONE_VIEW_SPLIT = 0).  Threshold 6 pixels:
+    most voxels of the view are "heavy" and go to the workgroups of k_gather_one (four wavefronts
     per voxel), which join the deal afterwards; counts exact, sums within 1e-4 of the oracle.  (The general path sums such a
-    voxel with 16 wavefronts, this one with 4: two fixed trees that differ in the last bits, so each is checked against the
+    voxel in parts, this one with 4 wavefronts: two fixed trees that differ in the last bits, so each is checked against the
     oracle, not against the other.)"""
     import voxproj_host
     dev = torch.device(DEV)
@@ -93,6 +94,7 @@ def test_one_view_heavy_voxels_take_the_workgroup_role_of_the_same_launch(oracle
         ws = voxproj_host.Workspace()
         ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, opt)
         ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, 6)
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, 0)
         count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 32, device=dev)
         heavy = 0
         for v in range(3):
@@ -173,3 +175,184 @@ def test_one_view_empty_and_tiny_outputs(oracle_mod):
         _call(t, s, ws, count, out, sync=True)
         assert int(count.sum().item()) == 0 and float((out - 3.0).abs().max().item()) == 0.0
     ws.release()
+
+
+@pytest.mark.parametrize("C,half,heavy_t,split_t,part_px", [
+    (32, False, None, 12, 5), (512, False, 6, None, 3), (512, True, None, 20, 7), (64, False, 10 ** 8, 8, 1), (7, False, 6, 30, 40),
+    (1000, False, None, 9, None), (32, False, None, None, 6)])
+def test_one_view_split_voxels_match_the_oracle(oracle_mod, C, half, heavy_t, split_t, part_px):
+    """Round 6: a one-view call cuts the voxels above a threshold into parts (one wavefront of k_gather_one per part,
+    k_combine_parts behind it); the others stay with the one-wavefront deal.  The threshold is VP_OPT_ONE_VIEW_SPLIT, else
+    VP_OPT_HEAVY_THRESHOLD, else twice the part size (at least 256 pixels on a view this small); the part size
+    VP_OPT_PART_PIXELS, else half the threshold (rounded up).
+    Counts and views-hit exact, the plan as the options say (P = ceil(c / part_px) per voxel above max(threshold, part)), rows of
+    one-wavefront voxels the oracle's bits, the others within 1e-4 of each row's largest element, two runs bit-identical."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    V = 3
+    s = make_scene(2000, V, 48, 32, seed=371 + C, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(V, 32, 48, C, seed=371 + C)[None]
+    if half:
+        feats = feats.astype(np.float16)
+    n_rows = s.n_vox + 1
+    ref_c, ref_o, ref_v = _oracle_views(oracle_mod, s, feats, range(V))
+    T = split_t if split_t is not None else heavy_t
+    px = part_px if part_px is not None else (T + 1) // 2
+    part_t = max(T, px) if T is not None else max(2 * px, 256)      # no threshold given: twice the part, 256 at least on a small view
+    runs = []
+    for grid in (None, 1002, None):
+        ws = voxproj_host.Workspace()
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, grid)
+        ws.set_option(voxproj_host.VP_OPT_HEAVY_THRESHOLD, heavy_t)
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, split_t)
+        ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, part_px)
+        count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, C, device=dev)
+        views = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        n_split = 0
+        light = np.ones(n_rows, bool)       # voxels that never left the one-wavefront deal
+        for v in range(V):
+            c1, _, _ = _oracle_views(oracle_mod, s, feats, [v])
+            _call(_tensors(s, feats, v, dev), s, ws, count, out, sync=True, views_hit=views)
+            ctr = voxproj_host.counters(ws, dev)
+            assert ctr["box_miss"] == 0
+            assert (ctr["part_t"], ctr["part_px"], ctr["heavy_t"]) == (part_t, px, part_t)
+            big = c1[c1 > part_t]
+            assert ctr["n_split"] == len(big) and ctr["n_parts"] == int(np.sum((big + px - 1) // px))
+            assert ctr["n_heavy"] == len(big)
+            n_split += len(big)
+            light &= c1 <= part_t
+        assert n_split >= (5 if T is not None else 1)
+        got_c, got_o, got_v = count.cpu().numpy(), out.cpu().numpy(), views.cpu().numpy()
+        assert np.array_equal(got_c, ref_c) and np.array_equal(got_v, ref_v)
+        assert got_o[light].tobytes() == ref_o[light].tobytes()
+        scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
+        assert (np.abs(got_o - ref_o) / scale).max() <= 1e-4
+        runs.append(got_o)
+        ws.release()
+    assert runs[0].tobytes() == runs[2].tobytes()      # same grid: the same fixed summation tree
+
+
+def test_one_view_parts_are_sized_from_the_views_hit_total(oracle_mod):
+    """No option set: the march counts the pixels whose ray hit a voxel, k_worklist sizes the parts from it -- part_px = max(32,
+    ceil(2 * hits / slots)) with 8192 slots for a one-view call of this size, threshold twice that but at least 256 pixels for a
+    view of up to 262144 pixels.  A 512 x 384 view of a small room (voxels of a thousand pixels and more), and the same room
+    with most of it removed (few hits: the smallest parts); blocking calls (the combine is launched only if the gather's note
+    says a voxel was split) and job-mode calls (always launched) leave the same bits."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 1, 512, 384, seed=401, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(1, 384, 512, 16, seed=401)[None]
+    n_rows = s.n_vox + 1
+    sparse = np.where(s.occ % 5 == 0, s.occ, 0).astype(s.occ.dtype)
+    for occ in (s.occ, sparse):
+        ref_c, ref_o, _ = _oracle_views(oracle_mod, s, feats, [0], occ=occ)
+        hits = int(ref_c.sum())
+        px = max(32, -(-2 * hits // 8192))
+        T = max(2 * px, 256)
+        ws = voxproj_host.Workspace()
+        count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 16, device=dev)
+        t = _tensors(s, feats, 0, dev, occ=occ)
+        _call(t, s, ws, count, out, sync=True)
+        ctr = voxproj_host.counters(ws, dev)
+        assert ctr["n_hit"] == hits and ctr["part_px"] == px and ctr["part_t"] == T and ctr["heavy_t"] == T
+        big = ref_c[ref_c > T]
+        assert len(big) > 20 and ctr["n_split"] == len(big) and ctr["n_parts"] == int(np.sum((big + px - 1) // px)) <= 8192
+        assert np.array_equal(count.cpu().numpy(), ref_c)
+        scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
+        got = out.cpu().numpy()
+        assert (np.abs(got - ref_o) / scale).max() <= 1e-4
+        count2, out2 = torch.zeros_like(count), torch.zeros_like(out)
+        _call(t, s, ws, count2, out2, sync=False, pipeline=True)
+        voxproj_host.workspace_status(ws, dev)
+        assert torch.equal(count2, count) and out2.cpu().numpy().tobytes() == got.tobytes()
+        ws.release()
+    assert hits < 196608 // 2      # the sparse room really is mostly misses (its parts are the smallest)
+
+
+def test_one_view_split_voxels_fp16_equals_fp32_bit_for_bit(oracle_mod):
+    """The fp16 feature-map mode widens exactly and sums in the same order, parts included."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 2, 48, 32, seed=381, room=(5.0, 4.0, 2.4))
+    f16 = make_features_np(2, 32, 48, 64, seed=381)[None].astype(np.float16)
+    n_rows = s.n_vox + 1
+    res = []
+    for feats in (f16, f16.astype(np.float32)):
+        ws = voxproj_host.Workspace()
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, 10)
+        ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 4)
+        count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 64, device=dev)
+        for v in range(2):
+            _call(_tensors(s, feats, v, dev), s, ws, count, out, sync=True)
+            assert voxproj_host.counters(ws, dev)["n_parts"] > 0
+        res.append((count.cpu().numpy(), out.cpu().numpy()))
+        ws.release()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1].tobytes() == res[1][1].tobytes()
+
+
+def test_one_view_split_voxels_box_misses_are_redone_by_the_combine(oracle_mod):
+    """An ID that labels several cells and is large enough to be split: its parts scan the box of the one cell the table remembers,
+    find fewer pixels than phase 1 counted, and k_combine_parts redoes the voxel over the whole image.  Counts exact, sums within
+    1e-4 (the redo sums with four wavefronts)."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 2, 40, 24, seed=341, room=(5.0, 4.0, 2.4))
+    occ = np.where(s.occ > 0, (s.occ % 7) + 1, 0).astype(np.int32)
+    feats = make_features_np(2, 24, 40, 8, seed=341)[None]
+    n_rows = 9
+    ref_c, ref_o, _ = _oracle_views(oracle_mod, s, feats, range(2), occ=occ, n_rows=n_rows)
+    ws = voxproj_host.Workspace()
+    ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, 16)
+    ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 8)
+    count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 8, device=dev)
+    miss = split = 0
+    for v in range(2):
+        _call(_tensors(s, feats, v, dev, occ=occ), s, ws, count, out, sync=True)
+        ctr = voxproj_host.counters(ws, dev)
+        miss += ctr["box_miss"]
+        split += ctr["n_split"]
+    assert miss > 0 and split > 0
+    assert np.array_equal(count.cpu().numpy(), ref_c)
+    scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(out.cpu().numpy() - ref_o) / scale).max() <= 1e-4
+    ws.release()
+
+
+def test_one_view_split_voxels_in_job_mode_and_row_ranges(oracle_mod):
+    """One-view calls with split voxels pipelined (march of view k+1 under the gather of view k), every other one cut into two
+    row ranges with a gather-only second half: the same bits as the blocking, uncut calls."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    V = 6
+    s = make_scene(2500, V, 56, 40, seed=391, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(V, 40, 56, 64, seed=391)[None]
+    n_rows = s.n_vox + 1
+    ref_c, _, ref_v = _oracle_views(oracle_mod, s, feats, range(V))
+    ts = [_tensors(s, feats, v, dev) for v in range(V)]
+    res = []
+    for mode in ("blocking", "job"):
+        ws = voxproj_host.Workspace()
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, 14)
+        ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 6)
+        count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 64, device=dev)
+        views = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        h = 1100
+        for v in range(V):
+            if mode == "blocking":
+                _call(ts[v], s, ws, count, out, sync=True, views_hit=views)
+                assert voxproj_host.counters(ws, dev)["n_parts"] > 0
+            elif v % 2:
+                ws.set_row_range(0, h)
+                _call(ts[v], s, ws, count, out, sync=False, pipeline=True, views_hit=views)
+                ws.set_row_range(h, n_rows)
+                _call(ts[v], s, ws, count, out, sync=False, pipeline=True, gather_only=True, views_hit=views)
+                ws.set_row_range()
+            else:
+                _call(ts[v], s, ws, count, out, sync=False, pipeline=True, views_hit=views)
+        voxproj_host.workspace_status(ws, dev)
+        res.append((count.cpu().numpy(), out.cpu().numpy(), views.cpu().numpy()))
+        ws.release()
+    assert np.array_equal(res[0][0], ref_c) and np.array_equal(res[1][0], ref_c)
+    assert np.array_equal(res[0][2], ref_v) and np.array_equal(res[1][2], ref_v)
+    assert res[0][1].tobytes() == res[1][1].tobytes()

@@ -420,7 +420,7 @@ def test_c_abi_from_a_plain_hip_program(tmp_path, oracle_mod):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
-    assert lines[0] == "abi 3 rows 290"
+    assert lines[0] == "abi 4 rows 290"
     Z, Y, X, H, W, C = 8, 17, 17, 16, 16, 4
     occ = np.zeros((1, Z, Y, X), np.int64)
     occ[0, 5] = 1 + np.arange(Y * X).reshape(Y, X)

@@ -6,8 +6,9 @@ the rays miss), clutter fraction 0.5.  Production thresholds, the call plan benc
 
 Bar (north_star): first-hit voxel IDs, pixel counts and view counts bit-exact against the oracle; feature sums of voxels summed by
 one wavefront bit-identical to the oracle's serial (b,v,y,x) order; sums of SPLIT voxels (parts combined in slot order, a fixed
-tree) within 1e-4 of the float64 accumulation, per element, relative to the row's magnitude -- and strictly per element wherever
-the element is not a cancellation residue (|sum| >= 1 % of the row's magnitude)."""
+tree) by the criterion of tests/sum_criteria.py: every element inside the float32 forward-error bound 4 sqrt(n) 2^-24 sum|addend|,
+within 1e-4 of the row's magnitude, within 1e-4 of itself wherever float32 can promise that, and -- where the oracle's serial
+float32 sum is at hand -- no worse than twice that order's own distance from the float64 sum."""
 import importlib.util
 import os
 import sys
@@ -16,6 +17,7 @@ import numpy as np
 import pytest
 import torch
 
+from sum_criteria import abs_sums_from_hits, assert_sums, assert_sums_vs_oracle
 from synthetic_scene import make_features_np, make_features_torch, make_scene
 
 pytestmark = pytest.mark.gpu
@@ -33,16 +35,6 @@ def _bench_module():
     finally:
         sys.argv = argv
     return m
-
-
-def _rows_within_bar(got, ref64, rows):
-    """rows of got (f32) vs ref64 (f64): 1e-4 of the row's magnitude per element, strictly per element off the residues."""
-    err = np.abs(got[rows].astype(np.float64) - ref64[rows])
-    row_mag = np.abs(ref64[rows]).max(axis=1, keepdims=True)
-    assert (err <= 1e-4 * row_mag).all(), float((err / row_mag).max())
-    solid = np.abs(ref64[rows]) >= 1e-2 * row_mag
-    assert (err[solid] <= 1e-4 * np.abs(ref64[rows])[solid]).all()
-    return float((err / row_mag).max())
 
 
 @pytest.mark.parametrize("name,views", [
@@ -94,7 +86,9 @@ def test_trajectory_shapes_eight_views_one_call_vs_oracle(oracle_mod, name, view
     assert int(count.max()) > 8 * ctr["heavy_t"]                # a close-up: single voxels far above the threshold
     got = out_t.cpu().numpy()
     assert got[~heavy].tobytes() == out[~heavy].tobytes(), "one-wavefront rows must equal the oracle's serial fp32 sums"
-    _rows_within_bar(got, r["out64"], heavy)
+    _, abs64 = abs_sums_from_hits(r["hits"][0], feats_t[0], n_rows, dev)
+    res = assert_sums(out_t, r["out64"], abs64, count, split=heavy, oracle32=out, dev=dev)
+    print(f"{name}: sum criterion {res}")
 
 
 def test_a1_whole_216_view_pass_counts_vs_oracle(oracle_mod):
@@ -196,6 +190,7 @@ def test_r2t_close_up_call_rows_vs_float64_reference(oracle_mod):
     assert ctr == ctr2 and torch.equal(first, out_t), "two runs of the same call must leave the same bits"
     del first
     ref = torch.zeros(n_rows, C, dtype=torch.float64, device=dev)
+    ref_abs = torch.zeros(n_rows, C, dtype=torch.float64, device=dev)
     count_ref = np.zeros(n_rows, np.int64)
     views_ref = np.zeros(n_rows, np.int64)
     sub = 20
@@ -209,6 +204,7 @@ def test_r2t_close_up_call_rows_vs_float64_reference(oracle_mod):
             ids = torch.from_numpy(hits[0, v].reshape(-1).astype(np.int64)).to(dev)
             rows = feats[0, a + v].reshape(-1, C).double()
             ref.index_add_(0, ids, rows)
+            ref_abs.index_add_(0, ids, rows.abs())
             del rows
     count_ref[0] = 0
     assert np.array_equal(count_t.cpu().numpy().astype(np.int64), count_ref)
@@ -217,18 +213,13 @@ def test_r2t_close_up_call_rows_vs_float64_reference(oracle_mod):
     assert ctr["n_heavy"] == int(heavy_np.sum()) > 100 and int(count_ref.max()) > 100000, (ctr, int(count_ref.max()))
     assert ctr["heavy_t"] == 2048 and ctr["n_parts"] > 10000      # 32 M pixels in parts of <= 2048
     ref[0] = 0
-    err = (out_t.double() - ref).abs()
-    row_mag = ref.abs().max(dim=1, keepdim=True).values
-    touched = torch.from_numpy(count_ref > 0).to(dev)
-    assert float(out_t[~touched].abs().max().item()) == 0.0
-    rel_row = err[touched] / row_mag[touched]
-    assert float(rel_row.max().item()) <= 1e-4, float(rel_row.max().item())
-    # per element, strictly, where the element is at least 10 % of the row's magnitude: with 10^3 - 10^5 float32 addends of
-    # |addend| ~ 0.04 per element the accumulated rounding is ~1e-6 - 1e-5 absolute whatever the order (the one-wavefront rows
-    # ARE the oracle's serial float32 sums bit for bit -- asserted in the eight-view test above -- and sit 1.05e-4 from the float64
-    # sum on an element of 1 % of its row; the reference's own atomics in arrival order: ~1e-3 on the longest rows)
-    solid = touched[:, None] & (ref.abs() >= 1e-1 * row_mag)
-    assert float((err[solid] / ref.abs()[solid]).max().item()) <= 1e-4
+    ref_abs[0] = 0
+    # tests/sum_criteria.py: the forward-error bound on every element, 1e-4 of the row's magnitude, 1e-4 of the element where
+    # float32 can promise it.  (Round 5 moved a solidity threshold here after a red run: an element of 1 % of its row, on a
+    # ONE-wavefront row that equals the oracle's serial float32 sum bit for bit, sits 1.05e-4 from the float64 sum -- float32's
+    # own distance, which the criterion now states instead of dodging.)
+    res = assert_sums(out_t, ref, ref_abs, count_ref, dev=dev)
+    print(f"R2T close-up call: sum criterion {res}")
 
 
 @pytest.mark.parametrize("B,V,part_px,heavy_t,half", [
@@ -292,8 +283,7 @@ def test_split_voxels_parts_of_every_size_against_the_oracle(oracle_mod, B, V, p
         assert ctr["n_parts"] == int(np.ceil(count[heavy] / float(px_eff)).sum()), ctr
     got = res[0][1]
     assert got[~heavy].tobytes() == out[~heavy].tobytes()
-    if heavy.any():
-        _rows_within_bar(got, r["out64"], heavy)
+    assert_sums_vs_oracle(got, r, feats, count, split=heavy, oracle32=out, dev=dev)
 
 
 def test_split_voxels_whose_boxes_miss_pixels_are_redone_over_whole_images(oracle_mod):
@@ -322,7 +312,7 @@ def test_split_voxels_whose_boxes_miss_pixels_are_redone_over_whole_images(oracl
     assert ctr["n_heavy"] == 5 and ctr["box_miss"] == 5 and ctr["n_parts"] > 10, ctr
     assert np.array_equal(count_t.cpu().numpy(), count)
     assert (views_t.cpu().numpy()[1:6] == 6).all()
-    _rows_within_bar(out_t.cpu().numpy(), r["out64"], count > 0)
+    assert_sums_vs_oracle(out_t, r, feats, count, dev=dev)
 
 
 def test_part_size_is_raised_to_the_slot_bound_when_it_binds(oracle_mod):
@@ -356,7 +346,7 @@ def test_part_size_is_raised_to_the_slot_bound_when_it_binds(oracle_mod):
     assert np.array_equal(count_t.cpu().numpy(), count)
     got = out_t.cpu().numpy()
     assert got[~heavy].tobytes() == out[~heavy].tobytes()
-    _rows_within_bar(got, r["out64"], heavy)
+    assert_sums_vs_oracle(got, r, feats, count, split=heavy, oracle32=out, dev=dev)
 
 
 def test_a_single_voxel_that_collects_nearly_the_whole_call(oracle_mod):
@@ -404,4 +394,4 @@ def test_a_single_voxel_that_collects_nearly_the_whole_call(oracle_mod):
     hits = voxproj_host.hit_image(ws, dev).cpu().numpy()
     assert np.array_equal(hits, r["hits"]) and np.array_equal(res[0][0], count)
     assert res[0][2][1] == V and res[0][1].tobytes() == res[1][1].tobytes()
-    _rows_within_bar(res[0][1], r["out64"], count > 0)
+    assert_sums_vs_oracle(res[0][1], r, feats, count, dev=dev)

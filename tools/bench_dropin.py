@@ -90,7 +90,7 @@ def run(shape, occ_modes, fronts, NV, reps, phases, view_ids=None):
                 p = voxproj_host.profile_read()
                 voxproj_host.profile_enable(False)
                 line += (f"  | per call, HIP events: prep {p['prep_ms'] / NV * 1e3:.1f} us, march+worklist {p['first_hit_ms'] / NV * 1e3:.1f} us, "
-                         f"gather {p['gather_ms'] / NV * 1e3:.1f} us, heavy launch {p['heavy_ms'] / NV * 1e3:.1f} us")
+                         f"gather {p['gather_ms'] / NV * 1e3:.1f} us, combine {p['heavy_ms'] / NV * 1e3:.1f} us")
             print(line, flush=True)
 
 
@@ -105,7 +105,13 @@ def main():
     ap.add_argument("--phases", action="store_true")
     ap.add_argument("--one-view", type=int, default=-1, help="VP_OPT_ONE_VIEW_GATHER of both fronts' workspaces: 0 = the general "
                     "gather kernel (A/B arm), n > 0 = the one-view kernel with n workgroups per CU, -1 = the library's default")
+    ap.add_argument("--one-view-split", type=int, default=-1, help="VP_OPT_ONE_VIEW_SPLIT of both fronts' workspaces: 0 = round 5's path "
+                    "(a workgroup per voxel above 320 pixels, no parts), n > 0 = split voxels above n pixels, -1 = the library's default "
+                    "(parts sized on the device from the view's hit total)")
     a = ap.parse_args()
+    if a.one_view_split >= 0:
+        m.set_workspace_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, a.one_view_split)
+        voxproj_host.set_default_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, a.one_view_split)
     if a.one_view >= 0:
         m.set_workspace_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view)
         voxproj_host.set_default_option(voxproj_host.VP_OPT_ONE_VIEW_GATHER, a.one_view)

@@ -8,7 +8,7 @@ import sys
 
 
 def short(name):
-    for k in ("k_first_hit", "k_combine_parts", "k_gather_one", "k_gather", "k_viewtab", "k_build_cells", "k_block_dist",
+    for k in ("k_zero_call", "k_first_hit", "k_combine_parts", "k_gather_one", "k_gather", "k_viewtab", "k_build_cells", "k_block_dist",
               "k_build_near", "k_project_colors", "k_color_cells", "k_worklist", "k_stream_read", "k_aggregate_view_f16",
               "k_upsample_hwc", "k_chw_to_hwc", "k_voxel_coords", "k_scatter_occupancy", "k_nearest_voxel"):
         if k in name:
