@@ -577,16 +577,22 @@ __device__ __forceinline__ void gather_part_wave(const GatherArgs &g, const Para
                     vm &= vm - 1;
                     const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
                     const int bx1 = __builtin_amdgcn_readlane(x1, l), by1 = __builtin_amdgcn_readlane(y1, l);
-                    const long long bw = bx1 - bx0 + 1, av = bw * (by1 - by0 + 1);
-                    // rows r of this box with lo <= a0 + r*bw < hi
-                    const long long r_lo = lo > a0 ? (lo - a0 + bw - 1) / bw : 0;
-                    const long long r_hi = hi < a0 + av ? (hi - a0 + bw - 1) / bw : (long long)(by1 - by0 + 1);
-                    a0 += av;
+                    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+                    const long long av = (long long)bw * bh;
+                    // rows r of this box with lo <= a0 + r*bw < hi.  A box that ends before lo owns none of them -- most views of a
+                    // part in the middle of a long voxel: no division for those; the others divide 32-bit numbers (lo - a0, hi - a0
+                    // < av < 2^31; two 64-bit divisions per view and part were a third of a part's instructions)
+                    const long long a1 = a0 + av;
+                    const long long b0 = a0;
+                    a0 = a1;
+                    if (a1 <= lo) continue;
+                    const int r_lo = lo > b0 ? (int)(((unsigned)(lo - b0) + (unsigned)bw - 1u) / (unsigned)bw) : 0;
+                    const int r_hi = hi < a1 ? (int)(((unsigned)(hi - b0) + (unsigned)bw - 1u) / (unsigned)bw) : bh;
                     if (r_lo >= r_hi) continue;
                     const long long bv = (long long)b * p.V + vbase + l;
                     const int before = found;
-                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0 + (int)r_lo, bx1,
-                                        by0 + (int)r_hi - 1, cb, lane, acc, found);
+                    scan_box<K, VEC, U>(feat_ptr<VEC>(g.feats, bv * HW * C), g.hit + bv * HW, W, C, id, bx0, by0 + r_lo, bx1,
+                                        by0 + r_hi - 1, cb, lane, acc, found);
                     if (cb == 0 && found > before) {
                         nviews++;
                         if (first_v < 0) first_v = (int)bv;
@@ -601,9 +607,10 @@ __device__ __forceinline__ void gather_part_wave(const GatherArgs &g, const Para
     if (lane == 0) g.pmeta[slot] = make_int4(found0, nviews, first_v, last_v);
 }
 
-// A part of a ONE-VIEW call (B*V == 1): the same cut as gather_part_wave makes for one view -- part k of P owns the box rows whose
-// first pixel's area index lies in [A k / P, A (k+1) / P) --, with the box computed once, by every lane alike, from the cell
-// k_worklist left in the item (one dependent load fewer in front of the first row).  No cell or no box: the part finds nothing and
+// A part of a ONE-VIEW call (B*V == 1): part k of P owns the rows [ceil(h k / P), ceil(h (k+1) / P)) of the voxel's pixel box of h
+// rows -- consecutive, disjoint, all of them, whatever P (more parts than rows: some own none) --, with the box computed once, by
+// every lane alike, from the cell k_worklist left in the item (one dependent load fewer in front of the first row; 32-bit
+// arithmetic: h k < 2^31 for any image the library accepts with P <= 8192 slots).  No cell or no box: the part finds nothing and
 // k_combine_parts redoes the voxel over the whole image.
 template <int K, int VEC, int U>
 __device__ __forceinline__ void gather_part_one(const GatherArgs &g, const Params &p, int slot, int lane)
@@ -621,12 +628,12 @@ __device__ __forceinline__ void gather_part_one(const GatherArgs &g, const Param
         if (voxel_box(g.viewtab[0], g.intr[0], g.intr[1], g.intr[2], g.intr[3], p.ox + (float)cxi * p.vs, p.oy + (float)cyi * p.vs,
                       p.oz + (float)czi * p.vs, box_half_edge(p), near_plane(p), W, H, a0, a1, a2, a3)) { x0 = a0; y0 = a1; x1 = a2; y1 = a3; }
     }
-    const long long bw = x1 - x0 + 1, bh = y1 - y0 + 1, A = bw * bh;
+    const int bh = y1 - y0 + 1;
     int r_lo = 0, r_hi = 0;
-    if (A > 0) {
-        const long long lo = A * part / P, hi = A * (part + 1) / P;
-        r_lo = (int)((lo + bw - 1) / bw);
-        r_hi = hi < A ? (int)((hi + bw - 1) / bw) : (int)bh;
+    if (bh > 0 && x1 >= x0) {
+        const unsigned up = (unsigned)P;
+        r_lo = (int)(((unsigned long long)(unsigned)bh * (unsigned)part + up - 1u) / up);
+        r_hi = (int)(((unsigned long long)(unsigned)bh * ((unsigned)part + 1u) + up - 1u) / up);
     }
     int found0 = 0;
     for (int cb = 0; cb < C; cb += CB) {

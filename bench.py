@@ -43,6 +43,14 @@ for _p in (ROOT, PKG):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+# measurement plumbing kept out of this file (tools/): the timed region and the line are here
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_calibrate import choose_arm  # noqa: E402
+from bench_cpu import (colour_projection_torch_cpu, cpu_baseline, cpu_colour_loop, cpu_torch_loop, distinct_image_lines,  # noqa: E402,F401
+                       host_cores)
+from bench_launch import launch_check, launch_ranks  # noqa: E402
+from bench_pmc import PMC_PROFILE, pmc_traffic, source_digest, write_pmc_json, write_r4_pmc_json  # noqa: E402
+
 WORKLOADS = {
     # name: (n_vox, n_views, W, H, C)
     "R2": (200000, 300, 968, 548, 512),      # BASELINE config 3 (metric config)
@@ -167,230 +175,6 @@ def parse():
     return a
 
 
-PMC_PROFILE = "r05_pmc_traffic.json"           # the round's committed counter passes (tools/profile_round.sh writes it)
-
-
-def source_digest():
-    """sha256 over the library's sources: a PMC profile only describes the kernels it was taken with."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(PKG, "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".h", ".hip")) or name == "Makefile":
-            with open(os.path.join(csrc, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
-
-
-def pmc_traffic(workload, chunk, dtype):
-    """HBM bytes per VIEW of a k_gather launch from the committed rocprofv3 PMC passes (profiles/<PMC_PROFILE>),
-    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2 for 16-B-per-lane streaming reads, KB units).
-    None unless the profile was taken on this workload / views-per-call / dtype AND with these very kernel sources
-    (the file records the digest of csrc/ it was measured on: a stale profile yields null, not a wrong number)."""
-    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
-    try:
-        with open(path) as f:
-            prof = json.load(f)
-    except OSError:
-        return None
-    run = prof.get("runs", {}).get(f"{workload}_{dtype}")
-    # the profile's launches may hold a few views more or fewer than this run's (the per-view figure is what is used)
-    if run is None or abs(run.get("views_per_call", 0) - chunk) > 4:
-        return None
-    if prof.get("source_digest") != source_digest():
-        return None
-    g = run["k_gather"]
-    return (2.0 * g["FETCH_SIZE_KB_per_launch"] + g["WRITE_SIZE_KB_per_launch"]) * 1024 / run["views_per_call"]
-
-
-PMC_RUNS = {   # key: (directory suffix of tools/profile_round.sh, views per launch of that pass = plan_calls' default for the leg)
-    "R2_f32": ("f32", 60), "R2_f16": ("f16", 100), "R1_f32": ("R1", 50), "R2T_f32": ("R2T", 60), "A1_f32": ("A1", 54)}
-
-
-def write_pmc_json(prof_dir, out_path):
-    """profiles/<tag>_pmc_traffic.json from the counter CSVs of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE passes per
-    leg: R2 fp32, R2 fp16, R1 fp32), stamped with the digest of the kernel sources they were measured on."""
-    import collections
-    import csv
-    import glob
-    runs = {}
-    for key, (sfx, vpc) in PMC_RUNS.items():
-        per = collections.defaultdict(lambda: collections.defaultdict(list))
-        for kind in ("fetch", "write"):
-            for f in glob.glob(os.path.join(prof_dir, f"{kind}_{sfx}", "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    name = r["Kernel_Name"]
-                    k = "k_combine_parts" if "k_combine_parts" in name else "k_gather_one" if "k_gather_one" in name else "k_gather" if "k_gather" in name else \
-                        "k_first_hit" if "k_first_hit" in name else None
-                    if k:
-                        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if "k_gather" in per and per["k_gather"].get("FETCH_SIZE") and per["k_gather"].get("WRITE_SIZE"):
-            # full launches only (two of them per pass; the pre-pass and the placement pass repeat them), at the views per
-            # launch the default plan gives that leg
-            runs[key] = {"views_per_call": vpc}
-            runs[key].update({k: {"launches": len(v["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), 1),
-                                  "WRITE_SIZE_KB_per_launch": round(sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"])), 1)}
-                              for k, v in per.items() if v.get("FETCH_SIZE") and v.get("WRITE_SIZE")})
-    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 0 "
-                     "--no-cpu-baseline --views 120 --chunk 60 | --views 200 --chunk 100 --dtype f16 | --workload R1 | --workload R2T | "
-                     "--workload A1, MI355X (tools/profile_round.sh); the trajectory legs' launches differ (close-ups, misses): their "
-                     "figures are means over the launches of one pass",
-           "note": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane streaming reads -> doubled by the reader "
-                   "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; units KB",
-           "source_digest": source_digest(), "runs": runs}
-    with open(out_path, "w") as f:
-        json.dump(doc, f, indent=1)
-    return doc
-
-
-def write_r4_pmc_json(prof_dir, out_path, views_per_call=1000):
-    """profiles/<tag>_r4_pmc.json from the counter CSVs of tools/r4_round.sh (k_project_colors), stamped with the digest of the
-    kernel sources: HBM-side bytes per launch and what the waves did with their cycles."""
-    import collections
-    import csv
-    import glob
-    c = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_project_colors" in r["Kernel_Name"]:
-                c[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    m = {k: sum(v) / len(v) for k, v in c.items()}
-    summary = {"wave_cycles_parked_on_memory": round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3),
-               "wave_cycles_issue_stalled": round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3),
-               # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs
-               "valu_busy_of_simd_cycles": round(m["SQ_ACTIVE_INST_VALU"] * 4 / (m["GRBM_GUI_ACTIVE"] / 8 * 1024), 3),
-               "valu_instructions_per_voxel_view": round(m["SQ_INSTS_VALU"] * 64 / (500000.0 * views_per_call), 1),
-               "l2_misses_per_launch": int(m["TCC_MISS_sum"]), "l2_hits_per_launch": int(m["TCC_HIT_sum"]), "waves": int(m["SQ_WAVES"])}
-    doc = {"source": "rocprofv3 --pmc passes of python3 bench.py --workload R4 --steps 1 --warmup 0 --no-cpu-baseline (tools/r4_round.sh), MI355X",
-           "source_digest": source_digest(), "views_per_call": views_per_call,
-           "FETCH_SIZE_KB_per_launch": round(m["FETCH_SIZE"], 1), "WRITE_SIZE_KB_per_launch": round(m["WRITE_SIZE"], 1), "summary": summary}
-    with open(out_path, "w") as f:
-        json.dump(doc, f, indent=1)
-    return doc
-
-
-def host_cores():
-    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (a one-GPU box of
-    the pool shows 256 logical CPUs but grants 16; 256 OpenMP threads on that share run the oracle 7x slower)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
-_cpu_maps = {}
-
-
-def cpu_baseline(scene, C, n_views, n_threads, maps=4):
-    """Time the CPU oracle (port of project_image_cuda_kernel.cu:24-92,157-187) on n_views views of the workload, `maps` at a time
-    (every chunk has its own poses and reads the same `maps` synthetic feature maps: generating 1 GB maps on the host costs
-    more than marching them, and the oracle's work does not depend on their values)."""
-    from oracle import oracle
-    from synthetic_scene import make_features_np
-    key = (scene.height, scene.width, C, maps)
-    if key not in _cpu_maps:
-        _cpu_maps.clear()
-        _cpu_maps[key] = make_features_np(maps, scene.height, scene.width, C, seed=0)[None]
-    feats = _cpu_maps[key]
-    n_rows = scene.n_vox + 1
-    count = np.zeros(n_rows, np.int32)
-    out = np.zeros((n_rows, C), np.float32)
-    occ = scene.occ[None].astype(np.int64)
-    dt = 0.0
-    for a in range(0, n_views, maps):
-        b = min(n_views, a + maps)
-        t0 = time.perf_counter()
-        oracle.project_features(feats[:, :b - a], occ, scene.c2w[a:b].reshape(-1), scene.intr[None], scene.opts(),
-                                scene.grid_origin, scene.voxel_size, count, out, want_hits=False, nthreads=n_threads)
-        dt += time.perf_counter() - t0
-    return dict(value=round(scene.n_vox * n_views / dt / 1e6, 4), unit="Mvoxel-views/s", cores=n_threads, kind="port",
-                sample=f"{n_views} of the workload's views at full resolution, all {scene.n_vox} voxels, "
-                       f"{dt:.1f} s wall (OpenMP over pixel rows + channel slices; {os.cpu_count()} logical CPUs "
-                       f"visible, {n_threads} granted to this process)")
-
-
-def colour_projection_torch_cpu(occ_zyx, c2w, intr4, grid_origin, voxel_size, img):
-    """The reference's colour loop (debug_project_colors.py:58-73: every occupied voxel centre through the pinhole model in
-    numpy float64, in-front test, banker's rounding to the nearest pixel, image-bounds test, img[v, u] / 255) as one vectorised
-    torch-CPU expression.  Returns (colors f32 [n,3], zyx i64 [n,3], uv i64 [n,2]) in the loop's raster order."""
-    zyx = (occ_zyx > 0).nonzero(as_tuple=False)
-    world = grid_origin.to(torch.float64)[None, :] + float(voxel_size) * zyx[:, [2, 1, 0]].to(torch.float64)      # DPC:60
-    m = c2w.reshape(4, 4).to(torch.float64)
-    d = world - m[:3, 3][None, :]
-    cam = torch.stack([m[0, i] * d[:, 0] + m[1, i] * d[:, 1] + m[2, i] * d[:, 2] for i in range(3)], 1)            # R^T d, DPC:61-63
-    fx, fy, cx, cy = (intr4.reshape(-1)[i].to(torch.float64) for i in range(4))
-    front = cam[:, 2] > 0                                                                                         # DPC:65
-    z = torch.where(front, cam[:, 2], torch.ones_like(cam[:, 2]))
-    u = torch.round(fx * (cam[:, 0] / z) + cx)                                                                    # DPC:66-68 (half to even)
-    v = torch.round(fy * (cam[:, 1] / z) + cy)
-    ok = front & (u >= 0) & (u < img.shape[1]) & (v >= 0) & (v < img.shape[0])                                    # DPC:69
-    ui, vi = u[ok].long(), v[ok].long()
-    colors = (img[vi, ui].to(torch.float64) / 255.0).to(torch.float32)                                            # DPC:70,75
-    return colors, zyx[ok], torch.stack([ui, vi], 1)
-
-
-def distinct_image_lines(scene, views, H, W, dev):
-    """Distinct 64-byte lines of the [V,H,W,3] uint8 images that hold a pixel some voxel samples in `views` -- the compulsory
-    image traffic of one vp_project_colors call (H*W*3 is a multiple of 64 for config 5, so lines never span two images)."""
-    occ = torch.from_numpy(scene.occ).to(dev)
-    c2w = torch.from_numpy(scene.c2w).to(dev)
-    intr = torch.from_numpy(scene.intr).to(dev)
-    origin = torch.from_numpy(np.asarray(scene.grid_origin, dtype=np.float32)).to(dev)
-    blank = torch.zeros(H, W, 3, dtype=torch.uint8, device=dev)
-    n = 0
-    for v in views:
-        uv = colour_projection_torch_cpu(occ, c2w[v], intr, origin, scene.voxel_size, blank)[2]
-        off = (uv[:, 1] * W + uv[:, 0]) * 3
-        n += int(torch.unique(torch.cat([off // 64, (off + 2) // 64])).numel())
-    return n
-
-
-def cpu_colour_loop(scene, img_u8, n_views, n_threads):
-    """cpu_torch_loop of the R4 leg: colour_projection_torch_cpu over n_views views on the box's host cores."""
-    torch.set_num_threads(n_threads)
-    occ = torch.from_numpy(scene.occ)
-    c2w = torch.from_numpy(scene.c2w)
-    intr = torch.from_numpy(scene.intr)
-    origin = torch.from_numpy(np.asarray(scene.grid_origin, dtype=np.float32))
-    img = torch.from_numpy(img_u8)
-    colour_projection_torch_cpu(occ, c2w[0], intr, origin, scene.voxel_size, img)        # warm
-    t0 = time.perf_counter()
-    seen = 0
-    for v in range(n_views):
-        seen += colour_projection_torch_cpu(occ, c2w[v], intr, origin, scene.voxel_size, img)[0].shape[0]
-    dt = time.perf_counter() - t0
-    return dict(value=round(scene.n_vox * n_views / dt / 1e6, 3), unit="Mvoxel-views/s", cores=n_threads,
-                what="the reference's colour loop (debug_project_colors.py:58-73) as one vectorised float64 torch-CPU expression per view",
-                sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {seen} voxel-views in the image")
-
-
-def cpu_torch_loop(scene, n_views, n_threads):
-    """The reference's only CPU projection loop (debug_project_features.py:59-84: every occupied voxel centre
-    through the pinhole model, in-front and in-image tests) as the vectorised torch-CPU expression of
-    debug_project_features.voxel_centre_diagnostics -- no occlusion test, no feature gather, so it is NOT the
-    same work as the projector; reported beside cpu_baseline because north_star names it."""
-    from debug_project_features import voxel_centre_diagnostics
-    torch.set_num_threads(n_threads)
-    occ = torch.from_numpy(scene.occ)
-    c2w = torch.from_numpy(scene.c2w)
-    intr = torch.from_numpy(scene.intr)
-    origin = torch.from_numpy(np.asarray(scene.grid_origin, dtype=np.float32))
-    voxel_centre_diagnostics(occ, c2w[0], intr, origin, scene.voxel_size, scene.width, scene.height)   # warm
-    t0 = time.perf_counter()
-    inb = 0
-    for v in range(n_views):
-        inb += voxel_centre_diagnostics(occ, c2w[v], intr, origin, scene.voxel_size, scene.width, scene.height)["n_in_bounds"]
-    dt = time.perf_counter() - t0
-    return dict(value=round(scene.n_vox * n_views / dt / 1e6, 3), unit="Mvoxel-views/s", cores=n_threads,
-                what="voxel-centre projection + bounds test only (DPF:59-84), float64 torch-CPU, vectorised",
-                sample=f"{n_views} views x {scene.n_vox} voxels, {dt:.2f} s wall, {inb} centres in bounds")
-
-
 def plan_calls(n_views, H, W, C, esize, chunk=0, call_gb=66.0, min_calls=2, pool=32):
     """(views per call, number of calls, resident maps) for a rank that projects ``n_views`` views: --chunk, or as many views
     as hold --call-gb of feature maps; at least --min-calls calls; then the views are spread evenly over the calls; the pool
@@ -422,6 +206,41 @@ def _max_over_ranks(dist, dt, dev):
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+R4_PMC_PROFILE = "r06_r4_pmc.json"            # tools/r4_round.sh
+
+
+def r4_roofline(ach, algo, call_ms, r4pmc, lines):
+    """The R4 line's roofline object.  SURVEY 8d waives the HBM claim for config 5 (3-12 B per voxel-view) and the counters say
+    what bounds the kernel instead: the L1s' miss queues -- every 4-byte sample pulls a 64-byte line, ~57 line misses are in
+    flight per L1 over the whole launch at ~870 cycles each, an L1 sits stalled behind lines already on their way half of the
+    launch (profiles/r05_ab_colour_order.log section 8).  So `bound` says that, `peak` is what those queues sustained in the
+    committed counter pass of THIS build -- misses in flight x 64 B / miss latency x 256 L1s, the clock taken from that pass's
+    cycles over this run's launch time -- and `frac` = algorithmic bytes per second against it (below 1 by the misses beyond the
+    distinct lines and by the launch's other kernels).  The HBM figures stay beside it as hbm_frac / hbm_peak."""
+    s_ = (r4pmc or {}).get("summary") or {}
+    peak = None
+    if s_.get("l1_misses_in_flight_per_l1") and s_.get("l1_miss_latency_cycles") and s_.get("launch_cycles"):
+        ghz = s_["launch_cycles"] / (call_ms * 1e-3) / 1e9
+        peak = s_["l1_misses_in_flight_per_l1"] * 64.0 / (s_["l1_miss_latency_cycles"] / ghz) * 256.0      # GB/s (bytes per ns)
+    return {"bound": "l1_miss_queue", "kernel": "vp_project_colors (k_color_cells + k_project_colors)", "achieved": round(ach, 1),
+            "peak": (round(peak, 1) if peak else None), "unit": "GB/s", "frac": (round(ach / peak, 4) if peak else None),
+            "peak_source": (f"profiles/{R4_PMC_PROFILE}: l1_misses_in_flight_per_l1 x 64 B / l1_miss_latency_cycles x 256 L1s at the clock "
+                            "that pass's cycles give this run's launch (Little's law on TCP_TCC_READ_REQ_LATENCY_sum / TCP_TCC_READ_REQ_sum / "
+                            "GRBM_GUI_ACTIVE) -- a measured ceiling of this build, not a datasheet number; null when the committed pass is "
+                            "of other kernel sources"),
+            "hbm_peak": HBM_PEAK_GBS, "hbm_frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": (int((r4pmc["FETCH_SIZE_KB_per_launch"] + r4pmc["WRITE_SIZE_KB_per_launch"]) * 1024) if r4pmc else None),
+            "traffic_source": f"profiles/{R4_PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, taken as read: "
+                              "the x2 correction of gfx950 applies to 16-B-per-lane streaming reads, these are 4-byte gathers, and "
+                              "FETCH_SIZE here equals TCC_MISS x 64 B) -- not measured in this run",
+            "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4), "counters": (s_ or None),
+            "distinct_image_lines_per_launch": lines,
+            "note": "one 4-byte load per voxel and view pulls a 64-byte line; with the voxels summed in Morton-curve order neighbouring "
+                    "lanes share lines (L2 misses 101 M -> 56 M per 1000 views, 1.03x the distinct lines) and the launch went from 2.0 to "
+                    "1.4-1.5 ms; fewer VALU instructions, deeper load rings and the cache-policy bits changed nothing or made it slower "
+                    "(profiles/r05_ab_colour_order.log).  SURVEY 8d: GB/s and voxel-views/s reported, no HBM roofline claim"}
 
 
 def bench_colors(a, dev, rank, world, dist):
@@ -494,7 +313,7 @@ def bench_colors(a, dev, rank, world, dist):
         ach = algo / (call_ms * 1e-3) / 1e9
         r4pmc = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_r4_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", R4_PMC_PROFILE)) as f:
                 r4pmc = json.load(f)
             if r4pmc.get("source_digest") != source_digest() or r4pmc.get("views_per_call") != chunk:
                 r4pmc = None
@@ -508,21 +327,7 @@ def bench_colors(a, dev, rank, world, dist):
                                       f"occlusion), room-shell scene seed 0", "views_per_call": chunk, "resident_images": pool,
                           "parallelism": f"views r::{world} per GPU + one RCCL {a.collective} of colour sums/counts per pass" if world > 1 else "single GPU"},
                "voxel_view_hits_per_step": n_seen,
-               "roofline": {"bound": "hbm", "kernel": "vp_project_colors (k_color_cells + k_project_colors)", "achieved": round(ach, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                            "traffic": (int((r4pmc["FETCH_SIZE_KB_per_launch"] + r4pmc["WRITE_SIZE_KB_per_launch"]) * 1024) if r4pmc else None),
-                            "traffic_source": "profiles/r05_r4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, taken as read: "
-                                              "the x2 correction of gfx950 applies to 16-B-per-lane streaming reads, these are 4-byte gathers, and "
-                                              "FETCH_SIZE here equals TCC_MISS x 64 B) -- not measured in this run",
-                            "bytes_per_launch": int(algo), "avg_launch_ms": round(call_ms, 4),
-                            "counters": (r4pmc.get("summary") if r4pmc else None),
-                            "distinct_image_lines_per_launch": (None if a.no_line_count else int(lines)),
-                            "note": "line-gather bound in the L1s, not in HBM: one 4-byte load per voxel and view pulls a 64-byte line; with the "
-                                    "voxels summed in Morton-curve order neighbouring lanes share lines (L2 misses 101 M -> 54 M, FETCH_SIZE 6.3 -> "
-                                    "3.4 GB per 1000 views) and the launch went from 2.0 to 1.4 ms, where an L1 spends about half of the launch stalled "
-                                    "behind lines already on their way (profiles/r05_ab_colour_order.log, section 8); skipping every view a "
-                                    "wavefront cannot see, deeper load pipelines and the cache-policy bits changed nothing or made it slower -- "
-                                    "SURVEY 8d waives the roofline claim for R4, `counters` (from the committed passes) and that log are the evidence"}}
+               "roofline": r4_roofline(ach, algo, call_ms, r4pmc, None if a.no_line_count else int(lines))}
         if not a.no_cpu_baseline and world == 1:
             from oracle import oracle
             nv = min(400, V)                                           # ~10 s on one core
@@ -659,55 +464,6 @@ def bench_entry(a, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
-def launch_ranks(a):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torchrun, rendezvous on
-    127.0.0.1), let rank 0's JSON line through on stdout and exit with the child's code.  Runs before this process has made
-    any GPU call and makes none (torch.cuda.device_count() does not initialise the device on this image): the parent never
-    replaces itself with another program, it waits.  Fewer visible GPUs than ranks is an error -- never a silent one-GPU run."""
-    import socket
-    import subprocess
-    if not a.launch_check:
-        need, have = (1 if a.single_device else a.gpus), torch.cuda.device_count()
-        if have < need:
-            print(f"bench.py --gpus {a.gpus}: needs {need} visible GPU(s), found {have} (one rank per GPU; --single-device "
-                  f"--dist-backend gloo rehearses the multi-rank path on one)", file=sys.stderr)
-            sys.exit(2)
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stdout.flush()
-    rc = subprocess.run(cmd, env=env).returncode           # stdout / stderr inherited: rank 0 prints the line
-    sys.exit(rc if rc >= 0 else 1)
-
-
-def launch_check(a, rank, world):
-    """--launch-check: the ranks' rendezvous, view shares and call plans without any GPU work (gloo, CPU tensors)."""
-    import torch.distributed as dist
-    from view_sharding import views_of_rank
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29519")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_vox, n_views, W, H, C = WORKLOADS[a.workload if a.workload in WORKLOADS else "R2"]
-    n_views = a.views or n_views
-    mine = views_of_rank(n_views, rank, world)
-    plan = plan_calls(len(mine), H, W, C, 4 if a.dtype == "f32" else 2, a.chunk, a.call_gb,
-                      a.min_calls if a.min_calls is not None else (1 if world > 1 else 2), a.pool) if mine else (0, 0, 0)
-    t = torch.zeros(world, 3, dtype=torch.int64)
-    t[rank] = torch.tensor([len(mine), plan[0], plan[1]])
-    dist.all_reduce(t)
-    if rank == 0:
-        assert int(t[:, 0].sum()) == n_views
-        print(json.dumps({"metric": "Mvoxel-views/sec", "value": None, "unit": "Mvoxel-views/s", "n_gpus": dist.get_world_size(),
-                          "launch_check": True, "gpus_requested": a.gpus, "views_per_rank": t[:, 0].tolist(),
-                          "views_per_call": t[:, 1].tolist(), "calls_per_rank": t[:, 2].tolist(),
-                          "config": {"workload": a.workload}}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == "--write-r4-pmc":
         print(json.dumps(write_r4_pmc_json(sys.argv[2], sys.argv[3])))
@@ -727,7 +483,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU, started by torchrun or by "
                          f"`python bench.py --gpus {a.gpus}` itself")
     if a.launch_check:
-        return launch_check(a, rank, world)
+        return launch_check(a, rank, world, WORKLOADS, plan_calls)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the projector has no CPU fallback")
     if not a.single_device and local >= torch.cuda.device_count():
@@ -976,26 +732,20 @@ def main():
     calibration = None
     if dist is not None and h_rows > 0 and arm_arg == "auto":
         # Which arm is faster depends on the links, the backend and the rank count (gloo rehearsals on one GPU: split 160 vs whole
-        # 171 ms at 2 ranks, 2117 vs 353 ms at 4) and no 8-GPU node was ever available to measure it: the timed arm is chosen from
-        # a short untimed calibration of both -- three steps each, alternating, every step bracketed like the timed region and
-        # MAX-reduced over the ranks (so that every rank picks the same arm), the median per arm.  Both arms still run and are
-        # reported.
-        calibration = {}
-        for arm_split in (True, False):
-            for _ in range(2):
-                step_dist(arm_split)                               # two steps each to settle (RCCL sizes its channels by message size; gloo
-                                                                   # sets up its staging per tensor: 17-s steps on first touches at 4 ranks)
-        per_arm = {True: [], False: []}
-        for rep in range(3):                                       # alternating, so that a drift hits both arms alike
-            for arm_split in (True, False):
-                barrier()
-                t_c = time.perf_counter()
-                step_dist(arm_split)
-                barrier()
-                per_arm[arm_split].append(_max_over_ranks(dist, time.perf_counter() - t_c, dev))
-        for arm_split in (True, False):                            # the median of three steps, MAX over ranks each
-            calibration["split" if arm_split else "whole"] = round(sorted(per_arm[arm_split])[1] * 1e3, 3)
-        default_split = calibration["split"] <= calibration["whole"]
+        # 171 ms at 2 ranks, 2117 vs 353 ms at 4) and no 8-GPU node was ever available to measure it: the timed arm is chosen by a
+        # short untimed calibration of both (tools/bench_calibrate.py: settle each arm until two consecutive steps agree, then the
+        # minimum of three alternating steps per arm; a step far above its arm's minimum -> no pick, the split arm).  Every step is
+        # bracketed like the timed region and MAX-reduced over the ranks, so every rank picks the same arm.  Both arms still
+        # run and are reported.
+        def timed_step(arm):
+            barrier()
+            t_c = time.perf_counter()
+            step_dist(arm == "split")
+            barrier()
+            return _max_over_ranks(dist, time.perf_counter() - t_c, dev)
+
+        calibration = choose_arm(timed_step)
+        default_split = calibration["pick"] == "split"
     for _ in range(a.warmup):
         step()
     barrier()
@@ -1130,7 +880,7 @@ def main():
                                "collective_ms_exposed": round(exposed_ms, 3),
                                "projection_ms_per_step": round(ms_step - exposed_ms, 3),
                                "timed_arm": "split" if split else "whole", "arms": arms,
-                               "timed_arm_chosen_by": ("calibration" if calibration is not None else "--collective-arm " + arm_arg),
+                               "timed_arm_chosen_by": (calibration["chosen_by"] if calibration is not None else "--collective-arm " + arm_arg),
                                "calibration": calibration,
                                "collectives_per_pass": ("feature sums in two pieces + one int32 tensor {pixel counts, view counts, views seen}"
                                                         if split else "feature sums + one int32 tensor {pixel counts, view counts, views seen}"),
@@ -1155,7 +905,7 @@ def main():
                          "level": (None if stream_gbs <= 0 else "fast" if ach / stream_gbs >= 0.98 else "mid" if ach / stream_gbs >= 0.93 else "slow"),
                          "traffic": (int(pmc_traffic(a.workload, chunk, a.dtype) * len(my_views) / len(calls))
                                      if (not a.views and world == 1 and pmc_traffic(a.workload, chunk, a.dtype)) else None),
-                         "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc passes of this build, rescaled to this "
+                         "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc passes of this build, rescaled to this "
                                            "run's views per launch; null when the kernel sources changed since) -- not measured in this run",
                          "bytes_per_launch": gather_bytes // len(calls), "avg_launch_ms": round(gather_ms, 4)},
         }

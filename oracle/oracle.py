@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+# ORACLE_LIB: another build of the same source (the sanitizer build of `make -C oracle sanitize`)
+_LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 

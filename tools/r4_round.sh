@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter evidence for config 5 (R4, the RGB path: k_project_colors), VERDICT r4 next #4.  On the GPU box from the repo root:
-#   bash tools/r4_round.sh r05
+#   bash tools/r4_round.sh r06
 set -o pipefail
 tag=${1:-r05}
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -17,7 +17,10 @@ step sq3 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_
 step fetch rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o c --output-format csv -- $one
 step write rocprofv3 --pmc WRITE_SIZE -d $out/write -o c --output-format csv -- $one
 step tcc rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $out/tcc -o c --output-format csv -- $one
-python3 tools/summarize_prof.py $out/trace $out/sq1 $out/sq2 $out/sq3 $out/fetch $out/write $out/tcc > $out/summary.txt 2>&1
+# the L1s' miss queues (round 6: the line's roofline is stated against what they sustain): misses, their summed latency, stall cycles
+step l1a rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum -d $out/l1a -o c --output-format csv -- $one
+step l1b rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE -d $out/l1b -o c --output-format csv -- $one
+python3 tools/summarize_prof.py $out/trace $out/sq1 $out/sq2 $out/sq3 $out/fetch $out/write $out/tcc $out/l1a $out/l1b > $out/summary.txt 2>&1
 python3 bench.py --write-r4-pmc $out gpurun_out/${tag}_r4_pmc.json
 find $out -name "*kernel_trace.csv" -size +5M -delete
 grep "k_project_colors\|k_color_cells\|^==\|^--" $out/summary.txt
