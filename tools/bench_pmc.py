@@ -43,7 +43,8 @@ def pmc_traffic(workload, chunk, dtype):
 
 
 PMC_RUNS = {   # key: (directory suffix of tools/profile_round.sh, views per launch of that pass = plan_calls' default for the leg)
-    "R2_f32": ("f32", 60), "R2_f16": ("f16", 100), "R1_f32": ("R1", 50), "R2T_f32": ("R2T", 60), "A1_f32": ("A1", 54)}
+    "R2_f32": ("f32", 60), "R2_f16": ("f16", 100), "R1_f32": ("R1", 50), "R2T_f32": ("R2T", 60), "A1_f32": ("A1", 54),
+    "R2T_f16": ("R2T_f16", 100), "A1_f16": ("A1_f16", 108)}
 
 
 def write_pmc_json(prof_dir, out_path):

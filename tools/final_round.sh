@@ -3,7 +3,7 @@
 # (GPU tests, rocprofv3 kernel trace + PMC traffic passes, every bench leg, the auxiliary benches).  Afterwards, in the build
 # container: bash tools/collect_profiles.sh r04
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r06}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
