@@ -3,14 +3,14 @@ tag=${1:-r06}
 # copies the summaries of tools/profile_round.sh $tag + tools/run_benches.sh (merged back under gpurun_out/) into profiles/
 P=profiles
 cp gpurun_out/${tag}_pmc_traffic.json $P/${tag}_pmc_traffic.json
-cp gpurun_out/prof_$tag/trace/t_kernel_stats.csv $P/${tag}_kernel_stats.csv; cp gpurun_out/prof_$tag/trace_f16/t_kernel_stats.csv $P/${tag}_kernel_stats_f16.csv; cp gpurun_out/prof_$tag/trace_R4/t_kernel_stats.csv $P/${tag}_kernel_stats_R4.csv
+cp gpurun_out/prof_$tag/trace_f32/t_kernel_stats.csv $P/${tag}_kernel_stats.csv; cp gpurun_out/prof_$tag/trace_f16/t_kernel_stats.csv $P/${tag}_kernel_stats_f16.csv; cp gpurun_out/prof_$tag/trace_R4/t_kernel_stats.csv $P/${tag}_kernel_stats_R4.csv
 cp gpurun_out/prof_$tag/trace_R1/t_kernel_stats.csv $P/${tag}_kernel_stats_R1.csv; cp gpurun_out/prof_$tag/trace_R2T/t_kernel_stats.csv $P/${tag}_kernel_stats_R2T.csv; cp gpurun_out/prof_$tag/trace_A1/t_kernel_stats.csv $P/${tag}_kernel_stats_A1.csv; cp gpurun_out/prof_$tag/trace_entry_parity/t_kernel_stats.csv $P/${tag}_kernel_stats_entry_parity.csv
 cp gpurun_out/prof_$tag/trace_R2T_f16/t_kernel_stats.csv $P/${tag}_kernel_stats_R2T_f16.csv; cp gpurun_out/prof_$tag/trace_A1_f16/t_kernel_stats.csv $P/${tag}_kernel_stats_A1_f16.csv
 for n in default f16 R1 R1_one_call R2T A1 R2T_f16 A1_f16 R4 entry_parity entry_parity_unpipelined entry_fast serial rehearse_dist; do grep '^{' gpurun_out/${tag}_bench_$n.log | tail -1 > $P/${tag}_bench_$n.json; done
 grep '^{' gpurun_out/${tag}_bench_prep.log | tail -1 > $P/${tag}_bench_prep.json; cp gpurun_out/${tag}_bench_dropin.log $P/${tag}_bench_dropin.log
 grep '^{' gpurun_out/${tag}_bench_stage5.log | tail -1 > $P/${tag}_bench_stage5.json; grep '^{' gpurun_out/${tag}_bench_entry_files.log | tail -1 > $P/${tag}_bench_entry_files.json
 tail -n 3 gpurun_out/${tag}_gputest.log > $P/${tag}_gputest_tail.txt
-grep '^{' gpurun_out/prof_$tag/bench_under_rocprof.log | tail -1 > $P/${tag}_bench_under_rocprof.json
+grep '^{' gpurun_out/prof_$tag/bench_f32_under_rocprof.log | tail -1 > $P/${tag}_bench_under_rocprof.json
 { echo "# rocprofv3 summaries, round ${tag#r0}, final build (MI355X, ROCm 7.2), produced by tools/profile_round.sh $tag + tools/summarize_prof.py"
   echo "# commands (cd \$GRAFT_REPO_ROOT; TMPDIR=/tmp):"
   echo "#   rocprofv3 --kernel-trace --stats -d <out>/trace     -- python3 bench.py --no-cpu-baseline              (same run's JSON line: profiles/${tag}_bench_under_rocprof.json)"

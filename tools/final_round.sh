@@ -12,7 +12,7 @@ timeout -k 10 900 python3 -m pytest tests -m gpu -q > gpurun_out/${tag}_gputest.
 # counter passes first: the bench legs after them find profiles/${tag}_pmc_traffic.json stamped with THIS build's digest and
 # report roofline.traffic
 echo "[final] profile round $(date +%T)"
-timeout -k 10 1500 bash tools/profile_round.sh $tag || echo "[final] profile_round failed"
+for part in a b c collect; do timeout -k 10 1500 bash tools/profile_round.sh $tag $part || echo "[final] profile_round $part failed"; done
 cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
 echo "[final] benches $(date +%T)"
 timeout -k 10 1200 bash tools/run_benches.sh $tag || echo "[final] run_benches failed"
