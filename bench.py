@@ -145,7 +145,8 @@ def parse():
                          "workgroup sums the voxel); 0 = the library's default, min(256 + 64 x views per call, 2048)")
     ap.add_argument("--part-pixels", type=int, default=0,
                     help="experiment: VP_OPT_PART_PIXELS of the workspace (pixels per part of a voxel above the heavy threshold); "
-                         "0 = the library's default, min(2048, threshold / 2)")
+                         "0 = the library's default: the heavy threshold, min(256 + 64 * views per call, 2048), raised to "
+                         "2 * pixels of the call / part slots where that binds")
     ap.add_argument("--march-lds-kb", type=int, default=-1,
                     help="experiment: VP_OPT_MARCH_LDS_KB of the workspace (dynamic-LDS reservation of the march = its occupancy "
                          "cap beside a gather); -1 = the library's default (41 KiB = 3 workgroups per CU)")
@@ -449,7 +450,8 @@ def bench_entry(a, dev, rank, world, dist):
                "entry": {"mode": a.entry, "ms_per_view": round(ms_view, 4), "rows_out": n_out,
                          "dropin_ms_per_view": round(best * 1e3, 4), "entry_over_dropin": round(ms_view / (best * 1e3), 3),
                          "dropin_what": "project_features_cuda (compiled module), one view per blocking call"},
-               "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3), "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
+               "step_ms": {"min": round(step_list[0], 3), "median": round(step_list[len(step_list) // 2], 3), "max": round(step_list[-1], 3)},
+            "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3), "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
                                      "gather": round(prof["gather_ms"] / a.steps, 3), "combine_parts": round(prof["heavy_ms"] / a.steps, 3),
                                      "note": "HIP events of an extra pass after the timed region"},
                "roofline": {"bound": "hbm", "kernel": "k_gather", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -752,11 +754,17 @@ def main():
     voxproj_host.profile_enable(True)
     state["exposed_s"] = 0.0
     state["proj_s"] = 0.0
+    # (an event at the head of every step and one behind the last: per-step device time for `step_ms` without touching the timed
+    # region -- the stream is never waited on between steps)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        step_ev[i].record()
         step()
+    step_ev[a.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_list = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(a.steps))
     voxproj_host.workspace_status(ws, dev)
     prof = voxproj_host.profile_read()
     voxproj_host.profile_enable(False)

@@ -60,8 +60,17 @@ def test_bench_gloo_rehearsal_started_by_bench_itself(ranks):
     assert 0 < c["collective_ms_exposed"] < d["ms_per_step"]
     assert d["hit_pixels_per_step"] > 0 and d["value"] > 0 and d["reduced_hit_pixels"] > 0
     arms, cal, timed = c["arms"], c["calibration"], c["timed_arm"]
-    assert set(arms) == {"split", "whole"} == set(cal) and c["timed_arm_chosen_by"] == "calibration"
-    assert timed == min(cal, key=cal.get), (timed, cal)               # the faster arm of the calibration is the timed one
+    assert set(arms) == {"split", "whole"} == set(cal["ms"]) and c["timed_arm_chosen_by"] == cal["chosen_by"]
+    assert timed == cal["pick"] and all(2 <= n <= 6 for n in cal["settling_steps"].values())
+    # the rule that picked it (tools/bench_calibrate.py): the smaller minimum when both arms are steady, the steady arm when one of
+    # them had a step more than 3x its own minimum, split when both had
+    unsteady = [arm for arm in ("split", "whole") if max(cal["samples_ms"][arm]) > 3.0 * min(cal["samples_ms"][arm])]
+    if not unsteady:
+        assert timed == min(cal["ms"], key=cal["ms"].get) and cal["chosen_by"].startswith("calibration"), cal
+    elif len(unsteady) == 1:
+        assert timed != unsteady[0] and cal["chosen_by"].startswith("the steady arm"), cal
+    else:
+        assert timed == "split" and cal["chosen_by"].startswith("fallback"), cal
     other = "whole" if timed == "split" else "split"
     assert arms[timed]["ms_per_step"] == d["ms_per_step"] and arms[other]["ms_per_step"] > 0
     # (whether the timed region then confirms the calibration is not asserted: N processes on one GPU over gloo's host staging
@@ -179,7 +188,10 @@ def _overlapped(d):
     its solo time, so the sum of the phases' own durations exceeds the pass by far; when the two streams share a hardware
     queue the phases run one after the other and the pass IS their sum."""
     ph = d["phase_ms_per_step"]
-    return d["ms_per_step"] < 0.9 * (ph["first_hit"] + ph["gather"])
+    # judged on the MEDIAN step of the timed region (HIP events at the head of every step): one slow step of five -- a box hiccup --
+    # does not decide, a lost overlap shows in every step; no second process is started (round 5 re-ran the bench once on failure,
+    # which would have hidden an overlap lost in half of the processes)
+    return d["step_ms"]["median"] < 0.9 * (ph["first_hit"] + ph["gather"])
 
 
 def test_job_mode_overlap_survives_a_single_hardware_queue():
@@ -188,15 +200,12 @@ def test_job_mode_overlap_survives_a_single_hardware_queue():
     instead of 52, profiles/r03_hw_queue_sharing.log).  The library's side stream has the device's highest priority: its
     queue comes from another pool, whatever the process created before."""
     env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
-    for attempt in range(2):      # (a pass without the overlap fails every time: 7 ms against 5; one slow step of three -- a box hiccup -- does not)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "3", "--warmup", "1",
-                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
-        d = _last_json(r.stdout)
-        assert d["phase_ms_per_step"]["overlapped"] is True
-        if _overlapped(d):
-            break
-    assert _overlapped(d), (d["ms_per_step"], d["phase_ms_per_step"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "5", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["phase_ms_per_step"]["overlapped"] is True
+    assert _overlapped(d), (d["ms_per_step"], d["step_ms"], d["phase_ms_per_step"])
 
 
 def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
@@ -204,17 +213,16 @@ def test_bench_multi_rank_path_over_a_one_rank_rccl_communicator():
     the pass, exact verification of the reduced counts, both collective arms) with backend nccl = RCCL and ONE rank -- the only way RCCL can run this code on a one-GPU
     box.  RCCL initialised before the first pipelined call used to cost the march/gather overlap (63 vs 54 ms per R2
     pass): asserted here on the R1 workload."""
-    for attempt in range(2):      # (see above: one slow step of three is a box hiccup, a lost overlap shows every time)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "3", "--warmup", "1",
-                            "--no-cpu-baseline", "--rehearse-dist", "--min-calls", "2"],      # two calls: something to overlap
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        d = _last_json(r.stdout)
-        if _overlapped(d):
-            break
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "R1", "--steps", "5", "--warmup", "1",
+                        "--no-cpu-baseline", "--rehearse-dist", "--min-calls", "2"],      # two calls: something to overlap
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["collective"]["backend"] == "nccl" and d["collective"]["op"] == "all-reduce"
     assert d["collective"]["collective_ms_exposed"] >= 0 and set(d["collective"]["arms"]) == {"split", "whole"}
-    assert d["collective"]["timed_arm"] == min(d["collective"]["calibration"], key=d["collective"]["calibration"].get)
+    cal = d["collective"]["calibration"]
+    assert d["collective"]["timed_arm"] == cal["pick"] and set(cal["ms"]) == {"split", "whole"} and cal["settling_steps"]["split"] >= 2
+    assert d["collective"]["timed_arm_chosen_by"] == cal["chosen_by"]
     assert d["reduced_hit_pixels"] == d["hit_pixels_per_step"]
     assert "rehearsal" in d["config"]["parallelism"] and "cpu_baseline" not in d
-    assert _overlapped(d), (d["ms_per_step"], d["phase_ms_per_step"])
+    assert _overlapped(d), (d["ms_per_step"], d["step_ms"], d["phase_ms_per_step"])

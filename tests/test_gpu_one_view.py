@@ -356,3 +356,46 @@ def test_one_view_split_voxels_in_job_mode_and_row_ranges(oracle_mod):
     assert np.array_equal(res[0][0], ref_c) and np.array_equal(res[1][0], ref_c)
     assert np.array_equal(res[0][2], ref_v) and np.array_equal(res[1][2], ref_v)
     assert res[0][1].tobytes() == res[1][1].tobytes()
+
+
+def test_blocking_one_view_call_behind_a_busy_stream_still_combines_its_parts(oracle_mod):
+    """A blocking one-view call launches k_combine_parts only when the gather's first wavefront reported split voxels through the
+    record's pinned page -- and launches it anyway when that note has not arrived within 2 ms.  Here the caller's stream is kept
+    busy for tens of milliseconds in front of the call (the gather cannot start, the note cannot arrive in time), then an idle
+    stream, then a view WITHOUT split voxels between two views with them on the same workspace (the note of one call must never
+    be taken for another's): every variant leaves the bits of the job-mode call, which always launches the combine."""
+    import voxproj_host
+    dev = torch.device(DEV)
+    s = make_scene(2000, 3, 48, 32, seed=403, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(3, 32, 48, 64, seed=403)[None]
+    n_rows = s.n_vox + 1
+    empty = np.zeros_like(s.occ)
+    ref_c, ref_o, _ = _oracle_views(oracle_mod, s, feats, [0, 2])
+
+    def run(mode):
+        ws = voxproj_host.Workspace()
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, 10)
+        ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 4)
+        count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 64, device=dev)
+        busy = torch.randn(4096, 4096, device=dev)
+        for v, occ in ((0, s.occ), (1, empty), (2, s.occ)):
+            t = _tensors(s, feats, v, dev, occ=occ)
+            if mode == "busy":
+                for _ in range(40):
+                    busy = busy @ busy * 1e-4          # ~20+ ms of work queued in front of the call on the same stream
+            if mode == "job":
+                _call(t, s, ws, count, out, sync=False, pipeline=True)
+                voxproj_host.workspace_status(ws, dev)
+            else:
+                _call(t, s, ws, count, out, sync=True)
+            ctr = voxproj_host.counters(ws, dev)
+            assert (ctr["n_split"] == 0 and ctr["n_parts"] == 0) if v == 1 else (ctr["n_split"] > 5 and ctr["n_parts"] > 20), ctr
+        res = (count.cpu().numpy(), out.cpu().numpy())
+        ws.release()
+        return res
+
+    job, idle, busy = run("job"), run("idle"), run("busy")
+    assert np.array_equal(job[0], ref_c) and np.array_equal(idle[0], ref_c) and np.array_equal(busy[0], ref_c)
+    assert job[1].tobytes() == idle[1].tobytes() == busy[1].tobytes()
+    scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
+    assert (np.abs(job[1] - ref_o) / scale).max() <= 1e-4
