@@ -450,8 +450,7 @@ def bench_entry(a, dev, rank, world, dist):
                "entry": {"mode": a.entry, "ms_per_view": round(ms_view, 4), "rows_out": n_out,
                          "dropin_ms_per_view": round(best * 1e3, 4), "entry_over_dropin": round(ms_view / (best * 1e3), 3),
                          "dropin_what": "project_features_cuda (compiled module), one view per blocking call"},
-               "step_ms": {"min": round(step_list[0], 3), "median": round(step_list[len(step_list) // 2], 3), "max": round(step_list[-1], 3)},
-            "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3), "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
+               "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3), "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
                                      "gather": round(prof["gather_ms"] / a.steps, 3), "combine_parts": round(prof["heavy_ms"] / a.steps, 3),
                                      "note": "HIP events of an extra pass after the timed region"},
                "roofline": {"bound": "hbm", "kernel": "k_gather", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -876,6 +875,7 @@ def main():
                        if world > 1 else "single GPU (one-rank process group: rehearsal of the multi-rank path)" if dist is not None
                        else "single GPU"},
             "achieved_hbm_gbs_whole_path": round(algo_step / (dt / a.steps) / 1e9, 1),
+            "step_ms": {"min": round(step_list[0], 3), "median": round(step_list[len(step_list) // 2], 3), "max": round(step_list[-1], 3)},
             "phase_ms_per_step": {"prep": round(prof["prep_ms"] / a.steps, 3),
                                   "first_hit": round(prof["first_hit_ms"] / a.steps, 3),
                                   "gather": round(prof["gather_ms"] / a.steps, 3),

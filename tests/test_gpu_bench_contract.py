@@ -138,8 +138,15 @@ def _check_common(d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
-    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
-    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    rf = d["roofline"]
+    assert d["value"] > 0 and rf["bound"] in ("hbm", "l1_miss_queue") and rf["achieved"] > 0
+    if rf["bound"] == "l1_miss_queue":
+        # config 5 (no HBM roofline claim): the line says what the counters say bounds the kernel; its peak comes from the
+        # committed counter pass of THIS build and is null for any other kernel sources; the HBM figure stays beside it
+        assert abs(rf["hbm_frac"] - rf["achieved"] / rf["hbm_peak"]) < 1e-3
+        assert (rf["peak"] is None and rf["frac"] is None) or abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    else:
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
 
 
 def test_bench_config2_r1_leg():

@@ -389,7 +389,7 @@ def test_blocking_one_view_call_behind_a_busy_stream_still_combines_its_parts(or
             else:
                 _call(t, s, ws, count, out, sync=True)
             ctr = voxproj_host.counters(ws, dev)
-            assert (ctr["n_split"] == 0 and ctr["n_parts"] == 0) if v == 1 else (ctr["n_split"] > 5 and ctr["n_parts"] > 20), ctr
+            assert (ctr["n_split"] == 0 and ctr["n_parts"] == 0) if v == 1 else (ctr["n_split"] >= 1 and ctr["n_parts"] > 20), ctr
         res = (count.cpu().numpy(), out.cpu().numpy())
         ws.release()
         return res
