@@ -300,7 +300,7 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     // The parts' partial rows live in the buffer set's part slots, and a call's parts must never outnumber them: a split voxel
     // has c > heavy_t >= part_px pixels and P = ceil(c / part_px) <= 2c / part_px parts, the c of a call add up to at most
     // B*V*H*W, so part_px >= 2*B*V*H*W / slots is enough -- both values are raised to that bound (only calls larger than the
-    // bench's are: 32768 slots allow parts of 2048 pixels up to 33.5 M pixels per call).
+    // bench's are: 65536 slots allow parts of 2048 pixels up to 67 M pixels per call).
     PlanArgs plan;
     plan.heavy_t = heavy_t; plan.part_t = 2147483647; plan.part_px = 0; plan.count_heavy = 1; plan.dyn_px_min = 0; plan.dyn_t_ratio = 0;
     plan.dyn_t_floor = 0; plan.cell_in_item = 0;

@@ -305,10 +305,15 @@ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 // Part slots of one buffer set (split voxels, vp_gather.h): a voxel above the heavy threshold is summed as P parts, each
 // part's C-wide partial row in a slot.  The number of slots bounds how finely a call can be cut: with part_px >= 2*B*V*H*W /
 // slots and heavy_t >= part_px the parts of a call can never outnumber the slots (project_impl raises both to that bound).
-// 32768 slots -- parts of 2048 pixels for calls of up to 33 M pixels (60 views of 968x548) --, fewer when the rows are wide
-// (64 MiB of partial rows per set at most) or the call is small.
+// 65536 slots -- parts of 2048 pixels for calls of up to 67 M pixels (126 views of 968x548: the 100-108 views a call of fp16 maps
+// holds; round 5's 32768 slots forced parts of 3238-3373 pixels on those calls: R2T fp16 25.3 -> 24.9 ms, A1 fp16 14.9 -> 13.9 ms
+// per pass, profiles/r06_f16_part_slots.log) --, fewer when the rows are wide (128 MiB of partial rows per set at most) or the
+// call is small.
 #ifndef VP_MAX_SLOTS
-#define VP_MAX_SLOTS 32768
+#define VP_MAX_SLOTS 65536
+#endif
+#ifndef VP_ONE_VIEW_SLOTS
+#define VP_ONE_VIEW_SLOTS 8192
 #endif
 inline long long part_slot_cap(int B, int V, int H, int W, int C)
 {
@@ -316,8 +321,8 @@ inline long long part_slot_cap(int B, int V, int H, int W, int C)
     const long long by_bytes = std::max<long long>(1024, ((long long)VP_MAX_SLOTS * 2048) / (std::max(C, 1) * 4ll));
     long long cap = std::max<long long>(64, std::min<long long>(VP_MAX_SLOTS, std::min(px2, by_bytes)));
     // a call of ONE view cuts voxels into parts of 256 pixels by default (128 at the least for a view of 524 k pixels): 8192 slots
-    // (16 MiB at C = 512) -- the drop-in module's scratch buffer should not carry 2 x 64 MiB it never touches
-    if ((long long)B * V == 1) cap = std::min<long long>(cap, 8192);
+    // (16 MiB at C = 512) -- the drop-in module's scratch buffer should not carry 2 x 128 MiB it never touches
+    if ((long long)B * V == 1) cap = std::min<long long>(cap, VP_ONE_VIEW_SLOTS);
     return cap;
 }
 

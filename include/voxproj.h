@@ -299,7 +299,7 @@ int vp_workspace_release(void *workspace);
  *                           VP_FLAG_SERIAL_SUMS overrides it with "never".  Never below the part size
  *   VP_OPT_PART_PIXELS      pixels per part of a split voxel (default: the threshold; 256 for calls of one view); raised to
  *                           2*B*V*H*W / slots when the call is so large that its parts could outnumber the workspace's part
- *                           slots (32768, fewer for rows wider than 2 KiB; 8192 for calls of one view)
+ *                           slots (65536, fewer for rows wider than 2 KiB; 8192 for calls of one view)
  *   VP_OPT_ONE_VIEW_SPLIT   calls of ONE view: voxels that collect more than this many pixels are cut into parts like those of
  *                           multi-view calls (one wavefront of the one-view gather per part, k_combine_parts behind it); the
  *                           voxels between VP_OPT_HEAVY_THRESHOLD and this value keep the workgroup role.  Default 1024;

@@ -324,8 +324,8 @@ def test_split_voxels_whose_boxes_miss_pixels_are_redone_over_whole_images(oracl
 
 
 def test_part_size_is_raised_to_the_slot_bound_when_it_binds(oracle_mod):
-    """Rows of 32 KiB (C = 8192): 64 MiB of partial rows per buffer set are 2048 part slots, and a call of 24 576 pixels asked to
-    cut voxels into 6-pixel parts could outnumber them -- both thresholds are raised to ceil(2 * B*V*H*W / slots) = 24 (reported
+    """Rows of 32 KiB (C = 8192): 128 MiB of partial rows per buffer set are 4096 part slots, and a call of 24 576 pixels asked to
+    cut voxels into 6-pixel parts could outnumber them -- both thresholds are raised to ceil(2 * B*V*H*W / slots) = 12 (reported
     through the counters), parts are planned with that size, results stay within the bar."""
     import voxproj_host
     dev = torch.device(DEV)
@@ -347,10 +347,10 @@ def test_part_size_is_raised_to_the_slot_bound_when_it_binds(oracle_mod):
                                       [float(v) for v in s.opts()], count_t, out_t, [float(v) for v in s.grid_origin], s.voxel_size,
                                       workspace=ws, sync=True)
     ctr = voxproj_host.counters(ws, dev)
-    bound = -(-2 * V * 64 * 48 // 2048)
-    assert bound == 24 and ctr["heavy_t"] == bound, ctr
+    bound = -(-2 * V * 64 * 48 // 4096)
+    assert bound == 12 and ctr["heavy_t"] == bound, ctr
     heavy = count > bound
-    assert ctr["n_heavy"] == int(heavy.sum()) > 50 and ctr["n_parts"] == int(np.ceil(count[heavy] / float(bound)).sum()) <= 2048
+    assert ctr["n_heavy"] == int(heavy.sum()) > 50 and ctr["n_parts"] == int(np.ceil(count[heavy] / float(bound)).sum()) <= 4096
     assert np.array_equal(count_t.cpu().numpy(), count)
     got = out_t.cpu().numpy()
     assert got[~heavy].tobytes() == out[~heavy].tobytes()

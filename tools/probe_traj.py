@@ -1,6 +1,6 @@
 """A/B of builds and split-voxel options on the calls of a trajectory leg, each call ALONE on the device, all arms on the SAME
 feature-pool allocation (its placement moves the gather by several per cent, so arms cannot be compared across processes):
-  python tools/probe_traj.py [--workload R2T|A1|R2] [--calls 0,1,2] [--rounds 3] ARM [ARM ...]
+  python tools/probe_traj.py [--workload R2T|A1|R2] [--calls 0,1,2] [--rounds 3] [--f16] ARM [ARM ...]
   ARM = path/to/lib.so[:heavy=N][:part=N]     (heavy / part: VP_OPT_HEAVY_THRESHOLD / VP_OPT_PART_PIXELS of the workspace)
 Prints, per call and arm, the mean k_gather time per launch (HIP events of the library), the fraction of 8 TB/s on the call's
 algorithmic bytes, and the number of parts.  --pipeline: also the WHOLE pass of the leg per arm, its calls pipelined
@@ -34,7 +34,9 @@ name = arg("--workload", "R2T")
 rounds = int(arg("--rounds", "3"))
 arms = [a for a in sys.argv[1:] if ".so" in a]
 n_vox, n_views, W, H, C = bm.WORKLOADS[name]
-V, n_calls, _ = bm.plan_calls(n_views, H, W, C, 4)
+half = "--f16" in sys.argv
+esize = 2 if half else 4
+V, n_calls, _ = bm.plan_calls(n_views, H, W, C, esize)
 call_ids = [int(v) for v in arg("--calls", ",".join(str(i) for i in range(n_calls))).split(",")]
 dev = torch.device("cuda", 0)
 s = bm.workload_scene(name)
@@ -43,8 +45,15 @@ c2w = torch.from_numpy(s.c2w).to(dev)
 intr = torch.from_numpy(s.intr[None]).to(dev)
 opts = [float(v) for v in s.opts()]
 origin = [float(v) for v in s.grid_origin]
-feats = torch.empty((1, V, H, W, C), dtype=torch.float32, device=dev)
-make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
+feats = torch.empty((1, V, H, W, C), dtype=torch.float16 if half else torch.float32, device=dev)
+if half:
+    tmp = torch.empty((1, H, W, C), dtype=torch.float32, device=dev)
+    for v in range(V):
+        make_features_torch(1, H, W, C, dev, seed=v, out=tmp)
+        feats[0, v] = tmp[0].half()
+    del tmp
+else:
+    make_features_torch(V, H, W, C, dev, seed=0, out=feats[0])
 count = torch.zeros(n_vox + 1, dtype=torch.int32, device=dev)
 out = torch.zeros(n_vox + 1, C, dtype=torch.float32, device=dev)
 res = {}
@@ -74,7 +83,7 @@ for rnd in range(rounds):
                     res.setdefault((ci, arm), []).append((p["gather_ms"], p["first_hit_ms"], p["heavy_ms"]))
             ph, nt = int(count.sum().item()), int((count > 0).sum().item())
             ctr = voxproj_host.counters(ws, dev)
-            info[(ci, arm)] = (ph * C * 4 + nt * C * 4 * 2 + len(views) * H * W * 4 + (n_vox + 1) * 8, ctr["n_parts"], ctr["n_heavy"], ctr["heavy_t"],
+            info[(ci, arm)] = (ph * C * esize + nt * C * 4 * 2 + len(views) * H * W * 4 + (n_vox + 1) * 8, ctr["n_parts"], ctr["n_heavy"], ctr["heavy_t"],
                                float(out.double().sum().item()))
         voxproj_host.profile_enable(False)
         if "--pipeline" in sys.argv:
@@ -105,7 +114,7 @@ if "--pipeline" in sys.argv:
         g = info[("pass", arm)]
         print(f"pass    {os.path.basename(arm):44s} {t.mean():8.3f} ms per pipelined pass (min {t.min():8.3f}, {len(t)} passes)  "
               f"gather {g[0]:7.3f}  march {g[1]:7.3f}  combine {g[2]:6.3f}  -> {n_vox * n_views / (t.mean() * 1e-3) / 1e6:8.1f} Mvoxel-views/s")
-print(f"# {name}: {V} views per call, calls {call_ids}, {rounds} rounds x 2 timed launches per arm, every call alone on the device")
+print(f"# {name}{' fp16 feature maps' if half else ''}: {V} views per call, calls {call_ids}, {rounds} rounds x 2 timed launches per arm, every call alone on the device")
 for ci in call_ids:
     for arm in arms:
         t = np.array(res[(ci, arm)])
