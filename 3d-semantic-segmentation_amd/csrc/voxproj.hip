@@ -279,16 +279,12 @@ static int project_impl(const float *feats, bool feats_f16, const int64_t *occ, 
     const long long row_hi = rec.opt_row_end < 0 ? (long long)n_rows : std::min<long long>(rec.opt_row_end, (long long)n_rows);
 
     // ---- phase 1 (on s1) ----
-    // More pixels than heavy_t in one call -> the voxel is not one wavefront's job.  One-view calls: a workgroup of the same
-    // launch sums it (k_gather_one), threshold 256 + 64.  Every other call cuts it into parts of part_px pixels (vp_gather.h,
-    // "Split voxels"), and both numbers default to min(256 + 64*B*V, 2048): the longest item a wavefront can be handed bounds
-    // the tail of the launch -- the last items run on an emptying machine at ~4 GB/s per wavefront, 2048 rows of 2 KiB in a
-    // millisecond.  On the close-up call of the R2T leg (60 frames staring at a wall from 0.27 m: 32 M pixels in 400 voxels,
-    // every one of them split), alone on the device: threshold / part 4096 / 2048 -> 11.5-11.7 ms, 2048 / 2048 -> 10.6-10.75,
-    // 1024 / 1024 -> 10.2-10.9, 512 / 512 -> 10.85 (0.70 / 0.76-0.77 / 0.75-0.80 / 0.75 of peak, two boxes, one allocation each);
-    // a call that is mostly misses, whose 2.8 ms were its longest voxel: 0.59 -> 0.75-0.77.  Whole pipelined passes: R2T 42.65 ->
-    // 41.40 ms with 2048 / 2048 (1024 / 1024: 41.45), the benign R2 room 55.58 -> 55.54 (1024 / 1024: 55.9: 12 k parts per call
-    // where 1.2 k do) -- profiles/r05_ab_split_voxels.log.
+    // More pixels than heavy_t in one call -> the voxel is not one wavefront's job: it is cut into parts of part_px pixels
+    // (vp_gather.h, "Split voxels").  Calls of more than one view: both numbers default to min(256 + 64*B*V, 2048) -- the longest
+    // item a wavefront can be handed bounds the tail of the launch; the last items run on an emptying machine at ~4 GB/s per
+    // wavefront, 2048 rows of 2 KiB in a millisecond (sweep of 512 ... 4096: profiles/r05_ab_split_voxels.log, fp16 calls:
+    // r06_f16_part_slots.log).  One-view calls: the device sizes both from the view's hit total (PlanArgs); 256 + 64 is the
+    // threshold of round 5's workgroup role, kept as the A/B arm (VP_OPT_ONE_VIEW_SPLIT = 0).
     int heavy_t = (int)std::min<long long>(256 + 64ll * B * V, 2048);
     if ((long long)B * V == 1) heavy_t = 256 + 64;
     if (rec.opt_heavy_t > 0) heavy_t = (int)std::min<long long>(rec.opt_heavy_t, 2147483647ll);   // VP_OPT_HEAVY_THRESHOLD

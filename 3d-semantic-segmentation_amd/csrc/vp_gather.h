@@ -2,7 +2,8 @@
 // (k_gather).  A voxel that collected more pixels than the heavy threshold in the call is cut into PARTS (round 5): each
 // part is an item of the same work list, summed by one wavefront into a partial row, and a small follow-up kernel
 // (k_combine_parts) adds the partial rows to the voxel's row in a fixed order.  One-view calls have a kernel of their
-// own (k_gather_one), whose first workgroups share the view's heavy voxels four wavefronts apiece.
+// own (k_gather_one): a fixed grid of wavefronts dealt the parts and the size-ordered list (round 6: parts sized on the device
+// from the view's hit total; round 5's path -- a workgroup of four wavefronts per large voxel -- is kept as the A/B arm).
 // Included by voxproj.hip only.
 #pragma once
 
@@ -226,7 +227,7 @@ struct GatherArgs {
     int host_seq;            // gather starts, tagged with the call's sequence number -- the host then launches k_combine_parts only if any
     int slot_cap;            // part slots of the buffer set: the consumers never walk past it, whatever the counters say
     int row_lo, row_hi;      // phase 2 of this launch covers the voxel IDs in [row_lo, row_hi) (VP_OPT_ROW_BEGIN / _END)
-    int heavy_blocks;        // k_gather_one: leading workgroups that take the view's heavy voxels
+    int heavy_blocks;        // k_gather_one, VP_OPT_ONE_VIEW_SPLIT = 0 only: workgroups that take the march's heavy voxels before they join the deal
     const int *work;         // work list of this call: WORK_CLASSES arrays of n_rows voxel IDs, by size class (k_worklist)
     const int *work_n;       // voxels per class; [WORK_CLASSES] = parts planned, [WORK_CLASSES + 1] = split voxels (ST_NPARTS, ST_NSPLIT)
     const int4 *parts;       // part items of the split voxels: {id, part, P, first slot of the voxel}; the item's index is its slot
@@ -239,8 +240,7 @@ struct GatherArgs {
     int *status;
 };
 
-constexpr int GW_MERGED = 4;     // wavefronts that share one heavy voxel inside k_gather_one (= one of its workgroups)
-constexpr int HEAVY_BLOCKS = 128; // leading workgroups of k_gather_one that take the view's heavy voxels
+constexpr int GW_MERGED = 4;     // wavefronts of a workgroup that share one voxel: k_combine_parts, its whole-image redo, and the A/B arm of k_gather_one
 constexpr int COMBINE_BLOCKS = 512; // grid of k_combine_parts (a workgroup per split voxel at a time)
 // One-view calls size their parts on the device, from the number of pixels the view's rays hit (k_worklist): the smallest part,
 // and how many parts' worth of pixels a voxel must exceed to be cut (VP_OPT_PART_PIXELS / VP_OPT_ONE_VIEW_SPLIT fix them)
@@ -648,8 +648,8 @@ __device__ __forceinline__ void gather_part_one(const GatherArgs &g, const Param
     if (lane == 0) g.pmeta[slot] = make_int4(found0, found0 > 0 ? 1 : 0, found0 > 0 ? 0 : -1, found0 > 0 ? 0 : -1);
 }
 
-// Heavy role (the first HEAVY_BLOCKS workgroups of k_gather_one): the GW wavefronts of a workgroup share one voxel that collected more than heavy_t pixels
-// in this call (a voxel next to a camera).  Per view the box rows are cut into GW contiguous ranges,
+// Workgroup role: the GW wavefronts of a workgroup share one voxel.  Used by k_combine_parts to redo a split voxel whose parts came
+// up short (whole images) and by k_gather_one's A/B arm (VP_OPT_ONE_VIEW_SPLIT = 0: every voxel above heavy_t pixels in the call).  Per view the box rows are cut into GW contiguous ranges,
 // each wavefront sums its range in raster order, and the partial rows are combined through LDS in
 // wavefront order -- a fixed summation tree, so results are reproducible run to run (they differ from
 // the serial order in the last bits only, well inside the 1e-4 bar).
@@ -1021,9 +1021,10 @@ __global__ __launch_bounds__(256) void k_combine_parts(GatherArgs g, Params p)
 //     voxel per lane (in k_gather the box computation is laid out lane = view: for one view, ~350 VALU instructions on ONE
 //     lane at the head of every voxel's chain);
 //   * while voxel j's rows stream, the ID tile and the output row of voxel j + 1 are already in flight.
-// Every voxel is still summed by one wavefront in (y, x) order from the row already in `out`: the oracle's bits.  Voxels
-// above the heavy threshold go to the first workgroups of the same launch (four wavefronts per voxel, as in k_gather),
-// which join the deal afterwards.
+// Every voxel up to the split threshold is still summed by one wavefront in (y, x) order from the row already in `out`: the
+// oracle's bits.  Voxels above it are cut into parts (round 6, gather_part_one): the parts lead the deal, k_combine_parts follows on
+// the stream.  With VP_OPT_ONE_VIEW_SPLIT = 0 (round 5's path, the A/B arm) the voxels above 320 pixels go to workgroups of the same
+// launch instead, four wavefronts per voxel, which join the deal afterwards.
 // ------------------------------------------------------------------------------------------------
 template <int K, int VEC, int U>
 __global__ __launch_bounds__(256) void k_gather_one(GatherArgs g, Params p)

@@ -182,8 +182,9 @@ int vp_workspace_status(void *workspace, void *stream);
  * stream synchronise: [0] = rays that hit an out-of-range ID, [1] = voxels whose search box
  * missed pixels and were rescanned over whole images (performance hint only; results are exact
  * either way), [2] = voxels that collected more pixels than the heavy threshold in this call (summed in
- * parts; one-view calls: by a whole workgroup up to VP_OPT_ONE_VIEW_SPLIT pixels, in parts above), [7] = the heavy
- * threshold in force, [24] = the parts planned in this call, [25] = the voxels they belong to.  No reference counterpart.
+ * parts), [7] = the heavy threshold in force, [8] = pixels of a one-view call whose ray hit a voxel (when the device sizes
+ * the parts from it), [9] / [10] = pixels above which a voxel was cut into parts / pixels per part in force, [24] = the parts
+ * planned in this call, [25] = the voxels they belong to.  No reference counterpart.
  */
 int vp_workspace_counters(void *workspace, int32_t *host_words, int n, void *stream);
 
@@ -293,17 +294,21 @@ int vp_workspace_release(void *workspace);
  * library reads no environment variable).  value < 0 (or 0 for the threshold) restores the default.
  *   VP_OPT_HEAVY_THRESHOLD  voxels that collect more than this many pixels in ONE call are not summed by a single wavefront: they
  *                           are cut into parts of VP_OPT_PART_PIXELS pixels, each part summed by a wavefront of the same gather
- *                           launch, the partial rows added to the voxel's row in a fixed order by a follow-up kernel (calls of
- *                           ONE view: shared by the four wavefronts of a workgroup).  Default min(256 + 64*B*V, 2048) -- the
- *                           longest job a wavefront can get bounds the tail of the launch --, 320 for calls of one view;
+ *                           launch, the partial rows added to the voxel's row in a fixed order by a follow-up kernel.  Default
+ *                           min(256 + 64*B*V, 2048) -- the longest job a wavefront can get bounds the tail of the launch --;
+ *                           calls of one view: see VP_OPT_ONE_VIEW_SPLIT;
  *                           VP_FLAG_SERIAL_SUMS overrides it with "never".  Never below the part size
  *   VP_OPT_PART_PIXELS      pixels per part of a split voxel (default: the threshold; 256 for calls of one view); raised to
  *                           2*B*V*H*W / slots when the call is so large that its parts could outnumber the workspace's part
  *                           slots (65536, fewer for rows wider than 2 KiB; 8192 for calls of one view)
  *   VP_OPT_ONE_VIEW_SPLIT   calls of ONE view: voxels that collect more than this many pixels are cut into parts like those of
- *                           multi-view calls (one wavefront of the one-view gather per part, k_combine_parts behind it); the
- *                           voxels between VP_OPT_HEAVY_THRESHOLD and this value keep the workgroup role.  Default 1024;
- *                           0 = never split (round 5's behaviour, the A/B arm); never below the part size
+ *                           multi-view calls (one wavefront of the one-view gather per part, k_combine_parts behind it), the
+ *                           others are summed by one wavefront in the oracle's order.  Default (< 0): decided on the device from
+ *                           the number of pixels of the view whose ray hit a voxel -- parts of max(32, 2 * hits / 8192) pixels
+ *                           (VP_OPT_PART_PIXELS fixes the size), threshold twice the part, at least 256 pixels for views of up
+ *                           to 262144 pixels; VP_OPT_HEAVY_THRESHOLD, when set, is taken as this threshold.  0 = never split:
+ *                           round 5's behaviour (the four wavefronts of a workgroup share a voxel above VP_OPT_HEAVY_THRESHOLD,
+ *                           default 320), the A/B arm.  Never below the part size
  *   VP_OPT_MARCH_LDS_KB     dynamic-LDS reservation of the march kernel in KiB = its occupancy cap (default beside a
  *                           running gather in VP_FLAG_PIPELINE mode: 41 KiB = 3 workgroups per CU, 30 KiB = 5 when a
  *                           feature row is at most 1 KiB -- fp16 maps of 512 channels --; 0 otherwise).  Valid: 0 .. 64
