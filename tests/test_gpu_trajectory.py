@@ -403,3 +403,50 @@ def test_a_single_voxel_that_collects_nearly_the_whole_call(oracle_mod):
     assert np.array_equal(hits, r["hits"]) and np.array_equal(res[0][0], count)
     assert res[0][2][1] == V and res[0][1].tobytes() == res[1][1].tobytes()
     assert_sums_vs_oracle(res[0][1], r, feats, count, dev=dev)
+
+
+@pytest.mark.parametrize("name,frames,half", [("R2T", [0, 100, 150], False), ("A1", [30, 200], False), ("R2T", [59, 200], True)])
+def test_one_view_frames_at_full_resolution_parts_vs_serial_sums(name, frames, half):
+    """Round 6 at production scale: ONE view per blocking call on frames of the trajectory legs (close-up dwell, walk, the look through
+    the opening, clutter), the device's own part sizes, against the same call with VP_FLAG_SERIAL_SUMS -- every voxel summed by one
+    wavefront in (y, x) order, the oracle's order (bit-identity of that path with the oracle is asserted at these shapes by the eight-view
+    tests above and at small shapes by tests/test_gpu_one_view.py).  First-hit images and counts identical, the plan as documented
+    (part = max(32, ceil(2 hits / 8192)), threshold twice that), rows at or below the threshold the same bits, split rows by the sum
+    criterion with the float64 sums taken from the call's own first-hit image."""
+    import voxproj_host
+    bm = _bench_module()
+    dev = torch.device(DEV)
+    n_vox, n_views, W, H, C = bm.WORKLOADS[name]
+    s = bm.workload_scene(name)
+    n_rows = n_vox + 1
+    feats = torch.empty((1, 1, H, W, C), dtype=torch.float32, device=dev)
+    make_features_torch(1, H, W, C, dev, seed=9, out=feats[0])
+    if half:
+        feats = feats.half()
+    occ_t, intr_t = torch.from_numpy(s.occ[None].astype(np.int64)).to(dev), torch.from_numpy(s.intr[None]).to(dev)
+    opts, origin = [float(v) for v in s.opts()], [float(v) for v in s.grid_origin]
+    ws = voxproj_host.Workspace()
+    n_split = 0
+    for f in frames:
+        vmi = torch.from_numpy(s.c2w[f]).reshape(-1).contiguous().to(dev)
+        res = []
+        for serial in (True, False):
+            count_t = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+            out_t = torch.zeros(n_rows, C, device=dev)
+            voxproj_host.project_features_raw(feats, occ_t, vmi, intr_t, opts, count_t, out_t, origin, s.voxel_size, workspace=ws, sync=True,
+                                              serial_sums=serial)
+            res.append((count_t, out_t, voxproj_host.counters(ws, dev), voxproj_host.hit_image(ws, dev)))
+        (c0, o0, ctr0, h0), (c1, o1, ctr1, h1) = res
+        assert torch.equal(h0, h1) and torch.equal(c0, c1) and ctr0["n_parts"] == 0 and ctr1["box_miss"] == 0
+        hits = int(c1.sum().item())
+        px = max(32, -(-2 * hits // 8192))
+        assert ctr1["n_hit"] == hits and ctr1["part_px"] == px and ctr1["part_t"] == 2 * px, (ctr1, hits)
+        big = c1 > 2 * px
+        assert ctr1["n_split"] == int(big.sum().item())
+        assert ctr1["n_parts"] == int(torch.div(c1[big] + px - 1, px, rounding_mode="floor").sum().item()) <= 8192
+        n_split += ctr1["n_split"]
+        assert torch.equal(o0[~big], o1[~big]), "rows at or below the split threshold must keep the serial order's bits"
+        ref64, abs64 = abs_sums_from_hits(h1[0].cpu().numpy(), feats[0], n_rows, dev)
+        assert_sums(o1, ref64, abs64, c1.cpu().numpy(), split=big.cpu().numpy(), oracle32=o0, dev=dev)
+    assert n_split > 100
+    ws.release()
