@@ -140,3 +140,32 @@ def test_wrapper_signature_is_ten_positional_arguments(dropin):
     for fn in (dropin.project_features_cuda, dropin.project_features_cuda_py):
         with pytest.raises(TypeError):
             fn(*_args()[:9])
+
+
+def test_the_product_path_has_no_cpu_fallback(tmp_path, monkeypatch):
+    """A missing libvoxproj.so and a CPU tensor both RAISE: nothing in the product path routes through the oracle or any other CPU
+    implementation (the oracle is test infrastructure; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs load it)."""
+    import torch
+    import voxproj_host
+    import project_features_front
+    # (1) the library is gone
+    monkeypatch.setattr(voxproj_host, "LIB_PATH", str(tmp_path / "libvoxproj.so"))
+    monkeypatch.setattr(voxproj_host, "_lib", None)
+    with pytest.raises(voxproj_host.VoxprojError, match="no CPU fallback"):
+        voxproj_host.lib()
+    with pytest.raises(voxproj_host.VoxprojError, match="is missing"):
+        voxproj_host.workspace_bytes(1, 1, 4, 4, 4, 2, 2, 2, 3)
+    monkeypatch.undo()
+    # (2) CPU tensors: the front refuses them with the reference wrapper's message (W.cpp:5: CHECK_CUDA), before any library call
+    feats = torch.zeros(1, 1, 4, 4, 4)
+    occ = torch.zeros(1, 2, 2, 2, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        project_features_front.project_features_cuda_py(feats, occ, torch.zeros(16), torch.zeros(1, 4), torch.zeros(5),
+                                                        torch.zeros(3, dtype=torch.int32), torch.zeros(3, 4), torch.tensor([False]),
+                                                        torch.zeros(3), 0.1)
+    # (3) no module under the package imports the oracle
+    pkg = os.path.join(ROOT, "3d-semantic-segmentation_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert "import oracle" not in src and "from oracle" not in src, name
