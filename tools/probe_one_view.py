@@ -1,7 +1,7 @@
 """A/B of builds and one-view options on single frames of a workload, ONE view per blocking call (what the unchanged reference
 pipeline issues, debug_project_features.py:201-208), all arms on the SAME feature map and output allocation:
   python tools/probe_one_view.py [--workload R2T|A1|R2|R1] [--view-ids 0,30,59,100,150,200] [--reps 5] [--f16] ARM [ARM ...]
-  ARM = path/to/lib.so[:heavy=N][:split=N][:part=N][:grid=N]
+  ARM = path/to/lib.so[:heavy=N][:split=N][:part=N][:grid=N][:serial=1]
         (VP_OPT_HEAVY_THRESHOLD / VP_OPT_ONE_VIEW_SPLIT / VP_OPT_PART_PIXELS / VP_OPT_ONE_VIEW_GATHER of the workspace)
 Per frame and arm: wall time of the blocking call (min and median over --reps), the library's HIP-event times per kernel group,
 the fraction of 8 TB/s on the call's algorithmic bytes, voxels above the heavy threshold / split voxels / parts, and
@@ -64,14 +64,18 @@ for arm in arms:
     voxproj_host.VP_ABI_VERSION = abi      # (an older build as the baseline arm: it has no VP_OPT_ONE_VIEW_SPLIT)
     voxproj_host.VP_OPT_ONE_VIEW_SPLIT = 7 if abi >= 4 else voxproj_host.VP_OPT_PART_PIXELS
     ws = voxproj_host.Workspace()
+    serial = False
     for kv in parts[1:]:
         k, v = kv.split("=")
+        if k == "serial":      # VP_FLAG_SERIAL_SUMS: every voxel by one wavefront, the oracle's order (the parity aggregator's calls)
+            serial = bool(int(v))
+            continue
         if k == "split" and abi < 4:
             continue
         ws.set_option(OPT[k], int(v))
     for vi in view_ids:
         vmi = c2w[vi].reshape(-1).contiguous()
-        call = lambda: voxproj_host.project_features_raw(feats, occ, vmi, intr, opts, count, out, origin, s.voxel_size, workspace=ws, sync=True)
+        call = lambda: voxproj_host.project_features_raw(feats, occ, vmi, intr, opts, count, out, origin, s.voxel_size, workspace=ws, sync=True, serial_sums=serial)
         out.zero_(); count.zero_()
         call()
         got_c, got_o = count.clone(), out.clone()
