@@ -411,3 +411,42 @@ def test_blocking_one_view_call_behind_a_busy_stream_still_combines_its_parts(or
     assert job[1].tobytes() == idle[1].tobytes() == busy[1].tobytes()
     scale = np.abs(ref_o).max(axis=1, keepdims=True) + 1e-30
     assert (np.abs(job[1] - ref_o) / scale).max() <= 1e-4
+
+
+def test_two_threads_issue_blocking_one_view_calls_on_their_own_workspaces(oracle_mod):
+    """Two host threads, each with its own workspace, stream and outputs, issue blocking one-view calls with split voxels at the same
+    time (ctypes releases the GIL around the foreign call; the compiled front does too): every workspace record has its own pinned
+    page, so each thread polls its own gather's note.  Both threads must leave exactly what a single thread leaves."""
+    import threading
+    import voxproj_host
+    dev = torch.device(DEV)
+    V = 6
+    s = make_scene(2000, V, 48, 32, seed=405, room=(5.0, 4.0, 2.4))
+    feats = make_features_np(V, 32, 48, 32, seed=405)[None]
+    n_rows = s.n_vox + 1
+    ts = [_tensors(s, feats, v, dev) for v in range(V)]
+
+    def work(res, key, stream):
+        ws = voxproj_host.Workspace()
+        ws.set_option(voxproj_host.VP_OPT_ONE_VIEW_SPLIT, 8)
+        ws.set_option(voxproj_host.VP_OPT_PART_PIXELS, 3)
+        with torch.cuda.stream(stream):
+            count, out = torch.zeros(n_rows, dtype=torch.int32, device=dev), torch.zeros(n_rows, 32, device=dev)
+            stream.synchronize()
+            for rep in range(5):
+                for v in range(V):
+                    _call(ts[v], s, ws, count, out, sync=True)
+            res[key] = (count.cpu().numpy(), out.cpu().numpy())
+        ws.release()
+
+    res = {}
+    work(res, "alone", torch.cuda.Stream(dev))
+    threads = [threading.Thread(target=work, args=(res, k, torch.cuda.Stream(dev))) for k in ("a", "b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    ref_c, _, _ = _oracle_views(oracle_mod, s, feats, range(V))
+    assert np.array_equal(res["alone"][0], 5 * ref_c)
+    for k in ("a", "b"):
+        assert np.array_equal(res[k][0], res["alone"][0]) and res[k][1].tobytes() == res["alone"][1].tobytes()
